@@ -1,0 +1,250 @@
+/*
+ * rtfs_amd.h -- C ABI of the MI355X-native per-pixel sampling path.
+ *
+ * This is the drop-in boundary for ONE hot path of Smaug123/ray-tracing-fsharp:
+ *   Scene.render -> renderPixel -> traceOnce -> traceRay -> hitObject ->
+ *   {BoundingBox.hits, Sphere.firstIntersection, InfinitePlane.intersection} -> Hittable.Reflection
+ * (reference: RayTracing/Scene.fs:62-236).  The reference has no FFI of its own; every entry point
+ * below names the reference function (file:line under /root/reference) whose role it takes, and
+ * INTEGRATION.md shows the F# P/Invoke binding a maintainer would add.
+ *
+ * Conventions: POD only, caller-allocated outputs, int status (0 = RT_OK), no exceptions cross the
+ * boundary, rt_last_error() is thread-local.  All geometry is IEEE double (Float.fs:82: `float` is
+ * 64-bit); all colour is 8-bit (Pixel.fs:9-15); accumulators are int32 (Pixel.fs:78-85).
+ *
+ * The library is libamdhip64-only: no torch types appear here.  Device pointers are plain `void*`
+ * so that any allocator (hipMalloc, torch.empty(..., device="cuda").data_ptr()) can own the memory.
+ */
+#ifndef RTFS_AMD_H
+#define RTFS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------ */
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = 1, /* the reference would `failwith` / throw (e.g. Program.fs:69) */
+    RT_ERR_NO_DEVICE = 2,        /* no HIP device visible: the product path never falls back to a CPU */
+    RT_ERR_HIP = 3,              /* a HIP runtime call failed; rt_last_error() carries hipGetErrorString */
+    RT_ERR_UNSUPPORTED = 4,      /* e.g. Texture.Arbitrary closures (Texture.fs:8,24) cannot cross a C ABI */
+    RT_ERR_IO = 5
+};
+
+/* ---- Hittable (Hittable.fs:3-6) ------------------------------------------------------------ */
+enum rt_hittable_kind {
+    RT_HITTABLE_SPHERE = 0,           /* Hittable.Sphere: bounded, goes into the BoundingBoxTree */
+    RT_HITTABLE_UNBOUNDED_SPHERE = 1, /* Hittable.UnboundedSphere: tested for every ray (Scene.fs:77-86) */
+    RT_HITTABLE_INFINITE_PLANE = 2    /* Hittable.InfinitePlane: never in the tree (Hittable.fs:17-18) */
+};
+
+/* SphereStyle (Sphere.fs:10-37), in declaration order. */
+enum rt_sphere_style {
+    RT_SPHERE_LIGHT_SOURCE = 0,       /* LightSource of Texture */
+    RT_SPHERE_LIGHT_SOURCE_CAP = 1,   /* LightSourceCap of Pixel */
+    RT_SPHERE_PURE_REFLECTION = 2,    /* PureReflection of albedo * texture */
+    RT_SPHERE_FUZZED_REFLECTION = 3,  /* FuzzedReflection of albedo * texture * fuzz * FloatProducer */
+    RT_SPHERE_LAMBERT_REFLECTION = 4, /* LambertReflection of albedo * texture * FloatProducer */
+    RT_SPHERE_DIELECTRIC = 5,         /* Dielectric of albedo * texture * ior * prob * FloatProducer */
+    RT_SPHERE_GLASS = 6               /* Glass of albedo * texture * ior * FloatProducer */
+};
+
+/* InfinitePlaneStyle (InfinitePlane.fs:3-13), in declaration order. */
+enum rt_plane_style {
+    RT_PLANE_LIGHT_SOURCE = 0,
+    RT_PLANE_PURE_REFLECTION = 1,
+    RT_PLANE_LAMBERT_REFLECTION = 2,
+    RT_PLANE_FUZZED_REFLECTION = 3
+};
+
+/*
+ * One element of the `Hittable array` handed to Scene.make (Scene.fs:15).
+ * Sphere.make style centre radius (Sphere.fs:325-337) / InfinitePlane.make style point normal
+ * (InfinitePlane.fs:114-119).  FloatProducer arguments of the styles do not cross the boundary:
+ * randomness comes from rt_render's `seed` (see DESIGN.md "Seeding").
+ */
+typedef struct rt_hittable {
+    uint32_t kind;      /* rt_hittable_kind */
+    uint32_t style;     /* rt_sphere_style or rt_plane_style, by kind */
+    double   point[3];  /* sphere centre | a point on the plane */
+    double   normal[3]; /* plane normal, already unitised by the caller (InfinitePlane.make takes a UnitVector); spheres: ignored */
+    double   radius;    /* spheres; may be negative (Sphere.fs:321 "flipped") */
+    double   albedo;    /* float<albedo>, must lie in [0,1] (Pixel.fs:143) */
+    double   fuzz;      /* FuzzedReflection */
+    double   ior;       /* Dielectric / Glass boundaryRefractance */
+    double   prob;      /* Dielectric refraction probability */
+    uint8_t  rgb[3];    /* Texture.Colour / LightSourceCap colour / plane colour */
+    uint8_t  reserved;
+    int32_t  texture;   /* -1: Texture.Colour rgb.  >=0: index into the rt_texture array (sphere styles with a texture only) */
+} rt_hittable;
+
+/* ---- Textures (Texture.fs:6-72): closures are enumerated ----------------------------------- */
+enum rt_texture_kind {
+    RT_TEXTURE_COLOUR = 0,    /* ParameterisedTexture.Colour */
+    RT_TEXTURE_CHECKERED = 1, /* ParameterisedTexture.Checkered (even, odd, gridSize), Texture.fs:56-62 */
+    RT_TEXTURE_IMAGE = 2,     /* ParameterisedTexture.Image rows (Texture.fs:63-67) */
+    RT_TEXTURE_UV_RAMP = 3    /* the two ParameterisedTexture.Arbitrary closures of SampleImages.fs:606-627 */
+};
+
+enum rt_ramp_source { RT_RAMP_CONST = 0, RT_RAMP_U = 1, RT_RAMP_V = 2 };
+
+typedef struct rt_texture {
+    uint32_t kind;          /* rt_texture_kind */
+    uint8_t  rgb[3];        /* COLOUR; UV_RAMP constants */
+    uint8_t  ramp_src[3];   /* UV_RAMP: per channel rt_ramp_source; U -> byte(u*255.0), V -> byte(v*255.0) (truncating) */
+    uint8_t  reserved[2];
+    int32_t  even, odd;     /* CHECKERED: indices into the same texture array (must be < own index) */
+    double   grid_size;     /* CHECKERED */
+    int32_t  width, height; /* IMAGE */
+    const uint8_t *texels;  /* IMAGE: height*width*3 bytes, laid out as ParameterisedTexture.Image img.[y].[x]
+                               i.e. AFTER ofImage's row reversal (Texture.fs:34); copied by rt_scene_create */
+    double   map_centre[3]; /* interpret = Sphere.planeMapInverse map_radius map_centre (Sphere.fs:55-61), */
+    double   map_radius;    /*   read from the texture a hittable points at (the root of a Checkered tree)  */
+} rt_texture;
+
+/* ---- Camera (Camera.fs:3-28) ----------------------------------------------------------------- */
+typedef struct rt_camera {
+    double  view_origin[3], view_dir[3];   /* View : Ray */
+    double  xaxis_origin[3], xaxis_dir[3]; /* ViewportXAxis : Ray */
+    double  yaxis_origin[3], yaxis_dir[3]; /* ViewportYAxis : Ray (only its direction is used, Scene.fs:140) */
+    double  viewport_width, viewport_height, focal_length;
+    int32_t samples_per_pixel;
+    int32_t bounce_depth;                  /* Camera.fs:58 hard-codes 150; callers may override */
+} rt_camera;
+
+/* Camera.makeBasic samplesPerPixel focalLength aspectRatio origin viewDirection viewUp (Camera.fs:34-59;
+ * Plane.makeNormalTo' Plane.fs:22-38; Plane.basis Plane.fs:82-97).  view_direction must be unit length. */
+int rt_camera_make_basic(int32_t samples_per_pixel, double focal_length, double aspect_ratio,
+                         const double origin[3], const double view_direction[3], const double view_up[3],
+                         rt_camera *out);
+
+/* ---- Scene (Scene.fs:5-28, BoundingBoxTree.fs:9-43) ------------------------------------------ */
+typedef struct rt_scene rt_scene;
+
+typedef struct rt_scene_info {
+    int32_t n_bounded;      /* Hittable.Sphere count (leaves of the tree) */
+    int32_t n_unbounded;    /* UnboundedSphere + InfinitePlane count, original order kept (Array.partition) */
+    int32_t n_nodes;        /* BoundingBoxTree nodes, leaves included (2*n_bounded-1) */
+    int32_t tree_depth;
+    int32_t n_textures;
+    int32_t lds_resident;   /* 1 if the flattened scene fits the 160 KiB LDS image and the LDS kernel is used */
+    int64_t scene_bytes;    /* bytes of the flattened device image (without texels) */
+    int64_t texel_bytes;
+} rt_scene_info;
+
+/* Scene.make (Scene.fs:15-28): partitions bounded/unbounded, builds the BoundingBoxTree on the host,
+ * flattens it (DFS pre-order + skip links) and keeps a host copy; device copies are made lazily per device. */
+int rt_scene_create(const rt_hittable *hittables, size_t n_hittables,
+                    const rt_texture *textures, size_t n_textures, rt_scene **out);
+void rt_scene_destroy(rt_scene *scene);
+int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
+/* Flattened tree for inspection/tests: skip[n_nodes], prim[n_nodes] (-1 for Branch), boxes[n_nodes*6] as
+ * (minx,maxx,miny,maxy,minz,maxz).  Any pointer may be NULL. */
+int rt_scene_get_tree(const rt_scene *scene, int32_t *skip, int32_t *prim, double *boxes);
+
+/* ---- Render (Scene.render, Scene.fs:196-236) ---------------------------------------------------- */
+typedef struct rt_stats {
+    uint64_t rays;        /* Scene.hitObject calls (Scene.fs:62) = primary + secondary rays */
+    uint64_t aabb_tests;  /* BoundingBox.hits calls (BoundingBox.fs:30) */
+    uint64_t prim_tests;  /* Hittable.hits calls (Hittable.fs:27): sphere + plane tests, unbounded included */
+    uint64_t reflections; /* Hittable.Reflection calls (Hittable.fs:8-12) = path vertices shaded */
+    uint64_t samples;     /* Scene.traceOnce calls (Scene.fs:118) */
+    uint64_t pixels;      /* pixels rendered by this call */
+    uint64_t pixels_early;/* pixels that stopped after 2*firstTrial+1 samples (Scene.fs:185-188) */
+    double   kernel_ms;   /* device time of the render kernel, HIP events on the launch stream */
+    double   total_ms;    /* wall time of the call, host side */
+} rt_stats;
+
+#define RT_RENDER_COUNTERS 1u /* fill rays/aabb_tests/prim_tests/reflections (slightly slower kernel variant) */
+
+/*
+ * Image geometry (Scene.fs:208-209,219,226): rows = 2*max_height_coord+1, cols = 2*max_width_coord+1;
+ * image row index r (0 = top) maps to row = max_height_coord - r - 1, column index c to col = c - max_width_coord.
+ *
+ * A call renders the image rows r = row_first + i*row_stride for i in [0, n_rows): (0, 1, rows) is the whole
+ * frame; (rank, world, ceil((rows-rank)/world)) is one rank's interleaved shard.  RNG streams are keyed by
+ * (seed, global pixel index r*cols+c, sample index), so a shard's output does not depend on the sharding.
+ *
+ * accum: n_rows*cols*4 int32 = PixelStats {Count; SumRed; SumGreen; SumBlue} (Pixel.fs:78-85).
+ * rgb:   n_rows*cols*3 uint8 = PixelStats.mean (Pixel.fs:103-108); may be NULL.
+ */
+int rt_render(const rt_scene *scene, const rt_camera *camera,
+              int32_t max_width_coord, int32_t max_height_coord, uint64_t seed,
+              int32_t device, int32_t row_first, int32_t row_stride, int32_t n_rows,
+              uint32_t flags, int32_t *accum_host, uint8_t *rgb_host, rt_stats *stats);
+
+/* Same, with outputs left in device memory (d_accum / d_rgb are device pointers on `device`) and the launch
+ * enqueued on `stream` (a hipStream_t, NULL = the null stream).  If `stats` is non-NULL the call synchronises
+ * the stream and fills it; with stats == NULL it returns right after the launch. */
+int rt_render_device(const rt_scene *scene, const rt_camera *camera,
+                     int32_t max_width_coord, int32_t max_height_coord, uint64_t seed,
+                     int32_t device, int32_t row_first, int32_t row_stride, int32_t n_rows,
+                     uint32_t flags, void *d_accum, void *d_rgb, void *stream, rt_stats *stats);
+
+/* ---- Output side (ImageOutput.fs:11-30,163-197) -------------------------------------------------- */
+uint8_t rt_gamma_correct(uint8_t b); /* PixelOutput.correct (ImageOutput.fs:11-18) */
+/* ImageOutput.writePpm gammaCorrect pixels file (ImageOutput.fs:163-197): P3, no trailing newline. */
+int rt_write_ppm(const char *path, const uint8_t *rgb, int32_t rows, int32_t cols, int32_t gamma_correct);
+/* Same bytes into a caller buffer; returns the length needed (excluding NUL) or a negative status. */
+int64_t rt_format_ppm(const uint8_t *rgb, int32_t rows, int32_t cols, int32_t gamma_correct,
+                      char *out, size_t out_capacity);
+
+/* ---- Runtime ------------------------------------------------------------------------------------- */
+int rt_device_count(void);         /* 0 when no HIP device is visible (never an error) */
+const char *rt_last_error(void);   /* thread-local message of the last failing call */
+int rt_abi_version(void);
+/* sizeof of the ABI structs as compiled: 0 rt_hittable, 1 rt_texture, 2 rt_camera, 3 rt_scene_info, 4 rt_stats (bindings check their mirrors). */
+size_t rt_abi_sizeof(int which);
+/* Tunables of the render kernel: threads per workgroup (512 or 1024) and pixels per wave work unit (<= 64).
+ * 0 keeps the default.  Process-wide; meant for bench sweeps. */
+int rt_set_launch_config(int32_t block_threads, int32_t chunk_pixels, int32_t blocks_per_cu);
+
+/*
+ * ---- Device unit hooks ---------------------------------------------------------------------------
+ * Run ONE device function of the path over n inputs on the GPU, so that the reference's unit tests
+ * (the .fs files under RayTracing.Test) can be replayed against the very code the render kernel inlines.
+ * All pointers are HOST pointers; the hooks copy in, launch, copy out.
+ */
+/* FloatProducer (Float.fs:14-76): from state[4] produce n doubles with Get(). */
+int rt_dev_float_producer(int32_t device, const uint32_t state[4], int32_t n, double *out);
+/* Stream seeding (DESIGN.md "Seeding"): state for (seed, pixel, sample). */
+int rt_dev_stream_state(int32_t device, uint64_t seed, int32_t n, const uint64_t *pixel, const uint32_t *sample,
+                        uint32_t *state_out /* n*4 */);
+/* BoundingBox.inverseDirections + hits (BoundingBox.fs:25-94). rays: n*6 (origin, unit dir); boxes: n*6 (min xyz, max xyz). */
+int rt_dev_bbox_hits(int32_t device, int32_t n, const double *rays, const double *boxes, int32_t *hit_out);
+/* Sphere.firstIntersection (Sphere.fs:349-386). spheres: n*4 (centre xyz, radius). t_out = NaN when ValueNone. */
+int rt_dev_sphere_first_intersection(int32_t device, int32_t n, const double *rays, const double *spheres, double *t_out);
+/* InfinitePlane.intersection (InfinitePlane.fs:125-136). planes: n*6 (point, unit normal). */
+int rt_dev_plane_intersection(int32_t device, int32_t n, const double *rays, const double *planes, double *t_out);
+/* Pixel.combine / Pixel.darken (Pixel.fs:136-151). a,b: n*3 bytes; albedo: n. */
+int rt_dev_pixel_combine(int32_t device, int32_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);
+int rt_dev_pixel_darken(int32_t device, int32_t n, const uint8_t *p, const double *albedo, uint8_t *out);
+/* Hittable.Reflection (Hittable.fs:8-12 -> Sphere.fs:150-300 | InfinitePlane.fs:43-99) for hittable `index` of the
+ * scene (index into the array given to rt_scene_create).  Per item: ray_in n*6, colour_in n*3, strike n*3,
+ * rng_state n*4 (in/out).  Outputs: absorbed[n] (1 = ValueSome colour), colour_out n*3, ray_out n*6. */
+int rt_dev_reflection(int32_t device, const rt_scene *scene, int32_t n, const int32_t *index,
+                      const double *ray_in, const uint8_t *colour_in, const double *strike,
+                      uint32_t *rng_state, int32_t *absorbed, uint8_t *colour_out, double *ray_out);
+/* Scene.hitObject (Scene.fs:62-91): hit_index = index into the rt_scene_create array or -1; strike n*3; counters optional (n*2: aabb, prim). */
+int rt_dev_hit_object(int32_t device, const rt_scene *scene, int32_t n, const double *rays,
+                      int32_t *hit_index, double *strike, uint32_t *counters);
+/* Scene.traceRay (Scene.fs:93-114) from White for given rays and RNG states. colour_out n*3. */
+int rt_dev_trace_ray(int32_t device, const rt_scene *scene, int32_t bounce_depth, int32_t n, const double *rays,
+                     uint32_t *rng_state, uint8_t *colour_out);
+/* Texture lookup incl. Sphere.planeMapInverse (Sphere.fs:55-61, Texture.fs:50-67): uv_out n*2, colour_out n*3. */
+int rt_dev_texture_colour_at(int32_t device, const rt_scene *scene, int32_t texture, int32_t n, const double *points,
+                             double *uv_out, uint8_t *colour_out);
+/* IEEE-754 conformance probes of the device arithmetic the path relies on: op 0: 1.0/x, 1: sqrt(x), 2: rint(x),
+ * 3: x/y, 4: pow5(x) = Math.Pow(x, 5.0) (Sphere.fs:290). a,b: n doubles (b may be NULL for unary ops). */
+int rt_dev_arith(int32_t device, int32_t op, int32_t n, const double *a, const double *b, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTFS_AMD_H */

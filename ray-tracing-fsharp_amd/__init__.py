@@ -1,0 +1,20 @@
+"""ray-tracing-fsharp_amd: the MI355X-native per-pixel sampling path of Smaug123/ray-tracing-fsharp.
+
+`csrc/` holds the hand-written HIP path and the C ABI (include/rtfs_amd.h); the modules here are the host-side
+mirror of the reference's construction/render API over that ABI.  Import fails loudly if librtfs_amd.so is missing.
+"""
+from . import _abi  # noqa: F401
+from ._lib import LIB_PATH, RtError, lib  # noqa: F401
+from .raytracing import (Camera, Colour, FloatProducer, Hittable, Image, ImageOutput, InfinitePlane, InfinitePlaneStyle,  # noqa: F401
+                         ParameterisedTexture, Pixel, PixelOutput, Point, RenderResult, Scene, Sphere, SphereStyle, Texture,
+                         UnitVector, Vector)
+from . import hooks, sample_images  # noqa: F401
+
+
+def device_count() -> int:
+    return int(lib.rt_device_count())
+
+
+def set_launch_config(block_threads: int = 0, chunk_pixels: int = 0, blocks_per_cu: int = 0) -> None:
+    from ._lib import check
+    check(lib.rt_set_launch_config(block_threads, chunk_pixels, blocks_per_cu))

@@ -1,0 +1,494 @@
+// rt_device.h -- device functions of the per-pixel sampling path, written for gfx950 (CDNA4, wave64).
+//
+// Each function names the reference F# it takes the role of (paths relative to /root/reference/RayTracing).
+// Arithmetic contract (DESIGN.md "Exactness"): IEEE double throughout, no contraction (the file is built with
+// -ffp-contract=off and carries the pragma below), no fmin/fmax (NaN ordering of BoundingBox.fs:57-58 is kept by
+// writing the compares as the reference does), 1.0/x and sqrt are the correctly rounded device sequences,
+// Math.Round = v_rndne_f64 (rint).  The structure is NOT the reference's: no heap Ray objects, no recursion,
+// a stackless skip-link walk over a pre-order tree image, byte colour packed in one VGPR, material handling
+// split into decide/refract/reflect/fuzz stages so that lanes with different SphereStyles share instructions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace rtd {
+
+#define RTD_INLINE __device__ __forceinline__
+#define RTD_AS3 __attribute__((address_space(3)))
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+
+// ---- Float.fs:82-96 ---------------------------------------------------------------------------------
+#define RTD_TOL 0.00000001
+RTD_INLINE bool feq(double a, double b) { return fabs(a - b) < RTD_TOL; }
+RTD_INLINE bool fpos(double a) { return a > RTD_TOL; }
+enum { CMP_GT = 0, CMP_EQ = 1, CMP_LT = 2 };
+RTD_INLINE int fcmp(double a, double b) {
+    if (fabs(a - b) < RTD_TOL) return CMP_EQ;
+    return (a < b) ? CMP_LT : CMP_GT;
+}
+
+// ---- Point.fs:18-45 ------------------------------------------------------------------------------------
+struct V3 { double x, y, z; };
+RTD_INLINE V3 mk(double x, double y, double z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
+RTD_INLINE double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RTD_INLINE V3 vsub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RTD_INLINE V3 vscale(double s, V3 v) { return mk(s * v.x, s * v.y, s * v.z); }
+// Ray.walkAlongRay (Ray.fs:42-43): o + (v * m) per component
+RTD_INLINE V3 walk(V3 o, V3 v, double m) { return mk(o.x + (v.x * m), o.y + (v.y * m), o.z + (v.z * m)); }
+// Vector.unitise (Point.fs:28-35) == Ray.make' / Ray.overwriteWithMake's direction part (Ray.fs:11-34)
+RTD_INLINE bool unitise(V3 v, V3 &out) {
+    double d = dot(v, v);
+    if (feq(d, 0.0)) return false;
+    double factor = 1.0 / sqrt(d);
+    out = vscale(factor, v);
+    return true;
+}
+
+// ---- FloatProducer (Float.fs:14-76) ------------------------------------------------------------------------
+struct Rng { uint32_t x, y, z, w; };
+RTD_INLINE uint32_t rng_next(Rng &r) { // generateInt32, Float.fs:14-20
+    uint32_t t = r.x ^ (r.x << 11);
+    r.x = r.y;
+    r.y = r.z;
+    r.z = r.w;
+    r.w = r.w ^ (r.w >> 19) ^ (t ^ (t >> 8));
+    return r.w;
+}
+// toInt is a byte reversal (Float.fs:22-27); toDouble divides by UInt32.MaxValue (Float.fs:29)
+RTD_INLINE double rng_get(Rng &r) { return (double) __builtin_bswap32(rng_next(r)) / 4294967295.0; }
+
+// Stream seeding (DESIGN.md "Seeding"): SplitMix64-finalised key of (seed, pixel, sample).
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) { // integer-only: also used by the host to derive the seed key
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+RTD_INLINE uint64_t seed_key(uint64_t seed) { return mix64(seed + 0x9E3779B97F4A7C15ull); }
+RTD_INLINE Rng stream_for(uint64_t seedKey, uint64_t pixel, uint32_t sample) {
+    uint64_t h = mix64(seedKey ^ (pixel * 0xD1B54A32D192ED03ull + 0x8CB92BA72F3D8DD7ull));
+    h = mix64(h ^ ((uint64_t) sample * 0xAEF17502108EF2D9ull + 0x2545F4914F6CDD1Dull));
+    uint64_t a = mix64(h + 0x9E3779B97F4A7C15ull);
+    uint64_t b = mix64(h + 2ull * 0x9E3779B97F4A7C15ull);
+    Rng r;
+    r.x = (uint32_t) (a & 0xFFFFFFFFull) % 2147483647u; // uint (rand.Next ()) < 2^31-1 (Float.fs:33-36)
+    r.y = (uint32_t) (a >> 32) % 2147483647u;
+    r.z = (uint32_t) (b & 0xFFFFFFFFull) % 2147483647u;
+    r.w = (uint32_t) (b >> 32) % 2147483647u;
+    if ((r.x | r.y | r.z | r.w) == 0u) r.w = 1u;
+    return r;
+}
+
+// UnitVector.random (Point.fs:49-59): cube sample -> normalise, retry when |v|^2 < 1e-8
+RTD_INLINE V3 random_unit(Rng &r) {
+    V3 out;
+    for (;;) {
+        double r1 = rng_get(r), r2 = rng_get(r), r3 = rng_get(r);
+        V3 v = mk((2.0 * r1) - 1.0, (2.0 * r2) - 1.0, (2.0 * r3) - 1.0);
+        if (unitise(v, out)) break;
+    }
+    return out;
+}
+
+// ---- Pixel.fs:136-151 ; colour = R | G<<8 | B<<16 in one register ------------------------------------------------
+#define RTD_WHITE 0x00FFFFFFu
+#define RTD_BLACK 0x00000000u
+#define RTD_HOTPINK (205u | (105u << 8) | (180u << 16)) /* Pixel.fs:61-66 */
+RTD_INLINE uint32_t pix_combine(uint32_t a, uint32_t b) { // Pixel.combine
+    uint32_t r = ((a & 0xFFu) * (b & 0xFFu)) / 255u;
+    uint32_t g = (((a >> 8) & 0xFFu) * ((b >> 8) & 0xFFu)) / 255u;
+    uint32_t bl = (((a >> 16) & 0xFFu) * ((b >> 16) & 0xFFu)) / 255u;
+    return r | (g << 8) | (bl << 16);
+}
+RTD_INLINE uint32_t round_byte(double v) { return ((uint32_t) (int32_t) rint(v)) & 0xFFu; } // Math.Round |> byte
+RTD_INLINE uint32_t pix_darken(double albedo, uint32_t p) { // Pixel.darken
+    uint32_t r = round_byte((double) (p & 0xFFu) * albedo);
+    uint32_t g = round_byte((double) ((p >> 8) & 0xFFu) * albedo);
+    uint32_t b = round_byte((double) ((p >> 16) & 0xFFu) * albedo);
+    return r | (g << 8) | (b << 16);
+}
+
+// Math.Pow(x, 5.0) (Sphere.fs:290).  x^5 carried in double-double (error ~2^-100) and rounded once, i.e. the
+// correctly rounded power; glibc's pow -- what .NET calls on Linux and what the oracle calls -- agrees with it
+// on every input tried (tests/test_gpu_parity.py::test_pow5_matches_libm).
+RTD_INLINE double pow5(double x) {
+    double h2 = x * x;
+    double l2 = fma(x, x, -h2);
+    double h4 = h2 * h2;
+    double l4 = fma(h2, h2, -h4) + 2.0 * (h2 * l2);
+    double s4 = h4 + l4;
+    double t4 = l4 - (s4 - h4);
+    double h5 = s4 * x;
+    double l5 = fma(s4, x, -h5) + t4 * x;
+    return h5 + l5;
+}
+
+// ---- flattened scene ------------------------------------------------------------------------------------
+// Image layout (bytes; every section 16-byte aligned; built by rt_host.hpp, staged verbatim into LDS):
+//   box  [n_nodes][3] d2   {min,max} per axis                     48 B/node  (3 x ds_read_b128, 48-B stride)
+//   link [n_nodes]    i2   {skip, prim}                             8 B/node  (ds_read_b64)
+//   geo  [n_obj][3]   d2   sphere {cx,cy}{cz,r^2}{radius,0} | plane {px,py}{pz,nx}{ny,nz}   48 B/object
+//   meta [n_obj]      i2   {kind|style<<2|flipped<<5, rgb|(texture+1)<<24}                   8 B/object
+//   mat  [n_obj][3]   double {albedo, fuzz|ior, prob}                                       24 B/object
+// Objects: bounded spheres first (tree leaves point at them), then the unbounded list in Scene.make order.
+struct TexRec { // global memory only
+    uint32_t kind;
+    uint32_t rgb;       // packed colour
+    uint32_t ramp;      // src0 | src1<<8 | src2<<16
+    int32_t even, odd;
+    int32_t width, height;
+    uint32_t texel_off; // byte offset into the texel blob
+    double grid;
+    double cx, cy, cz, map_radius; // interpret = Sphere.planeMapInverse map_radius (cx,cy,cz); 1.0/radius is formed on the device as Sphere.fs:57 does
+};
+
+template <bool LDS> struct Ptrs;
+template <> struct Ptrs<true> {
+    typedef const RTD_AS3 d2 *d2p;
+    typedef const RTD_AS3 i2 *i2p;
+    typedef const RTD_AS3 double *dp;
+};
+template <> struct Ptrs<false> {
+    typedef const d2 *d2p;
+    typedef const i2 *i2p;
+    typedef const double *dp;
+};
+
+template <bool LDS> struct SceneView {
+    typename Ptrs<LDS>::d2p box;
+    typename Ptrs<LDS>::i2p link;
+    typename Ptrs<LDS>::d2p geo;
+    typename Ptrs<LDS>::i2p meta;
+    typename Ptrs<LDS>::dp mat;
+    int n_nodes, n_bounded, n_unbounded;
+    const TexRec *tex;
+    const uint8_t *texels;
+};
+
+struct SceneOffsets { // byte offsets into the image
+    uint32_t box, link, geo, meta, mat, total;
+    int32_t n_nodes, n_bounded, n_unbounded;
+};
+
+#define RTD_KIND_SPHERE 0u
+#define RTD_KIND_PLANE 2u
+
+struct Counters { uint32_t rays, aabb, prim, refl; };
+
+// ---- BoundingBox.hits (BoundingBox.fs:30-94) ------------------------------------------------------------------
+// Branch-free restatement: the two early bail-outs only skip work, so evaluating all three slabs and AND-ing
+// "not bailed after x", "not bailed after y", "final test after z" gives the same bool.  Note the asymmetry the
+// reference has and this keeps: bail-outs use `0.0 >= tMax`, the final test uses `tMax >= 0.0`.
+RTD_INLINE bool bbox_hits(double ix, double iy, double iz, V3 o, d2 bx, d2 by, d2 bz) {
+    double tMin = -__builtin_inf(), tMax = __builtin_inf();
+    double t0 = (bx.x - o.x) * ix, t1 = (bx.y - o.x) * ix;
+    if (ix < 0.0) { double tmp = t1; t1 = t0; t0 = tmp; }
+    tMin = (t0 > tMin) ? t0 : tMin;
+    tMax = (t1 < tMax) ? t1 : tMax;
+    bool ok = !(tMax < tMin || 0.0 >= tMax);
+    t0 = (by.x - o.y) * iy; t1 = (by.y - o.y) * iy;
+    if (iy < 0.0) { double tmp = t1; t1 = t0; t0 = tmp; }
+    tMin = (t0 > tMin) ? t0 : tMin;
+    tMax = (t1 < tMax) ? t1 : tMax;
+    ok = ok && !(tMax < tMin || 0.0 >= tMax);
+    t0 = (bz.x - o.z) * iz; t1 = (bz.y - o.z) * iz;
+    if (iz < 0.0) { double tmp = t1; t1 = t0; t0 = tmp; }
+    tMin = (t0 > tMin) ? t0 : tMin;
+    tMax = (t1 < tMax) ? t1 : tMax;
+    return ok && (tMax >= tMin && tMax >= 0.0);
+}
+
+// ---- Sphere.firstIntersection (Sphere.fs:349-386); returns NaN for ValueNone ----------------------------------------
+RTD_INLINE double sphere_first_intersection(V3 o, V3 d, V3 c, double r2) {
+    V3 diff = vsub(o, c);
+    double b = dot(d, diff);
+    double cc = dot(diff, diff) - r2;
+    double disc = (b * b - cc);
+    double i = __builtin_nan("");
+    int cmp = fcmp(disc, 0.0);
+    if (cmp == CMP_EQ) i = (-b);
+    else if (cmp == CMP_GT) {
+        double s = sqrt(disc);
+        double i1 = s - b;
+        double i2 = -(b + s);
+        bool p1 = fpos(i1), p2 = fpos(i2);
+        if (p1 && p2) i = (fcmp(i1, i2) == CMP_GT) ? i2 : i1; // Less -> i1, Greater -> i2, Equal -> i1
+        else if (p1) i = i1;
+        else if (p2) i = i2;
+    }
+    return fpos(i) ? i : __builtin_nan(""); // NaN > tol is false
+}
+
+// ---- InfinitePlane.intersection (InfinitePlane.fs:125-136) -----------------------------------------------------
+RTD_INLINE double plane_intersection(V3 o, V3 d, V3 p0, V3 n) {
+    double den = dot(n, d);
+    if (feq(den, 0.0)) return __builtin_nan("");
+    double t = dot(n, vsub(p0, o)) / den;
+    return fpos(t) ? t : __builtin_nan("");
+}
+
+// ---- Scene.hitObject (Scene.fs:62-91) + Scene.bestCandidate (Scene.fs:30-60) ------------------------------------------
+// The recursive left-then-right walk becomes a stackless loop over the pre-order image: a hit box advances to the
+// next node (its left child, or -- for a leaf -- whatever follows it), a missed box jumps to its skip link.
+// Returns the object index or -1; `bestLen` is the ray parameter of the hit.
+template <bool LDS, bool COUNT>
+RTD_INLINE int hit_object(const SceneView<LDS> &sc, V3 o, V3 d, double &bestLen, Counters &cnt) {
+    if (COUNT) cnt.rays++;
+    double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z; // BoundingBox.inverseDirections (BoundingBox.fs:25-28)
+    double bestF = __builtin_inf();
+    int best = -1;
+    bestLen = __builtin_nan("");
+    int n = 0;
+    const int nn = sc.n_nodes;
+    while (n < nn) {
+        d2 bx = sc.box[n * 3 + 0], by = sc.box[n * 3 + 1], bz = sc.box[n * 3 + 2];
+        i2 lk = sc.link[n];
+        if (COUNT) cnt.aabb++;
+        if (bbox_hits(ix, iy, iz, o, bx, by, bz)) {
+            if (lk.y >= 0) { // Leaf: Hittable.hits (Hittable.fs:27-31) -> Sphere.firstIntersection
+                d2 g0 = sc.geo[lk.y * 3 + 0], g1 = sc.geo[lk.y * 3 + 1];
+                if (COUNT) cnt.prim++;
+                double t = sphere_first_intersection(o, d, mk(g0.x, g0.y, g1.x), g1.y);
+                double a = t * t;
+                if (a < bestF) { bestF = a; best = lk.y; bestLen = t; } // strict `<` on t^2 (Scene.fs:45-47); NaN fails
+            }
+            n = n + 1;
+        } else n = lk.x;
+    }
+    // UnboundedObjects, in array order, accepted only when Float.compare a bestFloat = Less (Scene.fs:77-86)
+    for (int u = 0; u < sc.n_unbounded; ++u) {
+        int obj = sc.n_bounded + u;
+        d2 g0 = sc.geo[obj * 3 + 0], g1 = sc.geo[obj * 3 + 1];
+        i2 m = sc.meta[obj];
+        if (COUNT) cnt.prim++;
+        double t;
+        if ((m.x & 3) == (int) RTD_KIND_PLANE) {
+            d2 g2 = sc.geo[obj * 3 + 2];
+            t = plane_intersection(o, d, mk(g0.x, g0.y, g1.x), mk(g1.y, g2.x, g2.y));
+        } else t = sphere_first_intersection(o, d, mk(g0.x, g0.y, g1.x), g1.y);
+        if (t == t) { // ValueSome
+            double a = t * t;
+            if (fcmp(a, bestF) == CMP_LT) { bestF = a; best = obj; bestLen = t; }
+        }
+    }
+    return best;
+}
+
+// ---- Textures (Texture.fs:50-67, Sphere.planeMapInverse Sphere.fs:55-61) --------------------------------------------
+// Rare (only textured spheres), transcendental-heavy: kept out of line so the common path stays small.
+__device__ __noinline__ uint32_t texture_colour_at(const TexRec *tex, const uint8_t *texels, int id, V3 p, double *uv) {
+    const TexRec root = tex[id];
+    if (root.kind == 0u) return root.rgb; // ParameterisedTexture.toTexture's Colour case (Texture.fs:71)
+    double inv = 1.0 / root.map_radius;
+    V3 v = vscale(inv, vsub(p, mk(root.cx, root.cy, root.cz)));
+    const double PI = 3.14159265358979323846;
+    double theta = acos(-v.y);
+    double phi = atan2(-v.z, v.x) + PI;
+    double x = (phi / (2.0 * PI));
+    double y = theta / PI;
+    if (uv) { uv[0] = x; uv[1] = y; }
+    int cur = id;
+    for (int depth = 0; depth < 16; ++depth) { // Checkered trees descend to strictly smaller indices
+        const TexRec t = tex[cur];
+        if (t.kind == 1u) { // Checkered (Texture.fs:56-62)
+            double sine = sin(t.grid * x) * sin(t.grid * y);
+            cur = (fcmp(sine, 0.0) == CMP_LT) ? t.even : t.odd;
+            continue;
+        }
+        if (t.kind == 2u) { // Image (Texture.fs:63-67): truncating int conversions
+            int xi = (int) ((1.0 - x) * (double) (t.width - 1));
+            int yi = (int) (y * (double) (t.height - 1));
+            const uint8_t *px = texels + t.texel_off + ((size_t) yi * (size_t) t.width + (size_t) xi) * 3;
+            return (uint32_t) px[0] | ((uint32_t) px[1] << 8) | ((uint32_t) px[2] << 16);
+        }
+        if (t.kind == 3u) { // the UV ramps of RayTracing.App/SampleImages.fs:606-627: byte (x * 255.0)
+            uint32_t c = 0;
+            for (int k = 0; k < 3; ++k) {
+                uint32_t src = (t.ramp >> (8 * k)) & 0xFFu;
+                uint32_t ch = (t.rgb >> (8 * k)) & 0xFFu;
+                if (src == 1u) ch = ((uint32_t) (int32_t) (x * 255.0)) & 0xFFu;
+                else if (src == 2u) ch = ((uint32_t) (int32_t) (y * 255.0)) & 0xFFu;
+                c |= ch << (8 * k);
+            }
+            return c;
+        }
+        return t.rgb; // Colour
+    }
+    return RTD_BLACK;
+}
+
+// ---- Hittable.Reflection (Hittable.fs:8-12 -> Sphere.reflection Sphere.fs:150-300, InfinitePlane.reflection
+//      InfinitePlane.fs:43-99) --------------------------------------------------------------------------------
+// Returns true when the path is absorbed (ValueSome colour -> `colour` holds it); otherwise o/d/colour are the
+// outgoing LightRay.  Stages: decide (colour, random draw, which of refract/reflect/fuzz/lambert follow), then each
+// stage once, so Pure/Fuzzed/Dielectric/Glass spheres and Pure/Fuzzed planes all share one mirror computation.
+enum { ACT_REFLECT = 1, ACT_REFRACT = 2, ACT_FUZZ = 4, ACT_LAMBERT = 8, ACT_LAMBERT_ONCE = 16 };
+
+template <bool LDS>
+RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, V3 &d, uint32_t &colour, Rng &rng) {
+    const i2 m = sc.meta[obj];
+    const bool isPlane = (m.x & 3) == (int) RTD_KIND_PLANE;
+    const int style = (m.x >> 2) & 7;
+    const d2 g0 = sc.geo[obj * 3 + 0], g1 = sc.geo[obj * 3 + 1], g2 = sc.geo[obj * 3 + 2];
+    const double albedo = sc.mat[obj * 3 + 0], p1 = sc.mat[obj * 3 + 1], p2 = sc.mat[obj * 3 + 2];
+    uint32_t texColour = (uint32_t) m.y & 0x00FFFFFFu;
+    const int texId = (int) (((uint32_t) m.y) >> 24) - 1;
+    // Styles that carry a Texture: every SphereStyle but LightSourceCap (Sphere.fs:10-37), and the plane LightSource
+    // (InfinitePlane.fs:5); the other plane styles carry a plain Pixel.  The host rejects a texture id elsewhere.
+    if (texId >= 0 && (isPlane ? style == 0 : style != 1))
+        texColour = texture_colour_at(sc.tex, sc.texels, texId, strike, nullptr);
+
+    V3 n;              // normal.Vector (possibly flipped)
+    bool inside = false;
+    int act = 0;
+    double cosI = 0.0; // incomingCos handed to refract
+    double ior = p1, fuzz = p1;
+
+    if (isPlane) {
+        n = mk(g1.y, g2.x, g2.y);
+        // InfinitePlaneStyle order: LightSource, PureReflection, LambertReflection, FuzzedReflection
+        if (style == 0) { colour = pix_combine(colour, texColour); return true; } // InfinitePlane.fs:52-56
+        colour = pix_darken(albedo, pix_combine(colour, texColour));              // newColour, InfinitePlane.fs:40-41
+        if (style == 1) act = ACT_REFLECT;
+        else if (style == 3) act = ACT_REFLECT | ACT_FUZZ;
+        else act = ACT_LAMBERT_ONCE;
+    } else {
+        const V3 c = mk(g0.x, g0.y, g1.x);
+        const double r2 = g1.y, radius = g2.x;
+        const bool flipped = (m.x >> 5) & 1; // Float.compare radius 0.0 = Less (Sphere.fs:321), set by the host
+        if (!unitise(vsub(strike, c), n)) n = mk(0.0, 0.0, 0.0); // Sphere.normal (Sphere.fs:65-66)
+        V3 co = vsub(c, o);
+        int cmp = fcmp(dot(co, co), r2); // Sphere.fs:165-179
+        if ((cmp != CMP_GT) != flipped) { inside = true; n = vscale(-1.0, n); }
+
+        if (style == 0) { colour = pix_combine(colour, texColour); return true; } // LightSource, Sphere.fs:185-189
+        if (style == 1) {                                                         // LightSourceCap, Sphere.fs:190-200
+            double lower = c.x + (radius - (radius / 4.0));
+            colour = (fcmp(strike.x, lower) == CMP_GT) ? pix_combine(texColour, colour) : RTD_BLACK;
+            return true;
+        }
+        colour = pix_darken(albedo, pix_combine(colour, texColour)); // every remaining style: combine then darken
+        if (style == 4) act = ACT_LAMBERT;                           // Sphere.fs:202-222
+        else if (style == 2) act = ACT_REFLECT;                      // Sphere.fs:224-233
+        else if (style == 3) act = ACT_REFLECT | ACT_FUZZ;           // Sphere.fs:235-246
+        else if (style == 5) {                                       // Dielectric, Sphere.fs:248-267
+            double r = rng_get(rng);
+            if (r > p2) act = ACT_REFLECT;
+            else { cosI = dot(d, n); act = ACT_REFRACT; }
+        } else {                                                     // Glass, Sphere.fs:269-300
+            cosI = dot(vscale(-1.0, d), n);
+            double r = rng_get(rng);
+            double sr = inside ? 1.0 / ior : ior;
+            double param = (1.0 - sr) / (1.0 + sr);
+            param = param * param;
+            double prob = param + (1.0 - param) * pow5(1.0 - cosI);
+            act = (r < prob) ? ACT_REFLECT : ACT_REFRACT;
+        }
+    }
+
+    // Plane.makeOrthonormalSpannedBy normal ray (Plane.fs:64-79): shared by refract and the mirror
+    V3 v2 = mk(0.0, 0.0, 0.0);
+    bool haveV2 = false;
+    if (act & (ACT_REFLECT | ACT_REFRACT)) {
+        double coefficient = dot(n, d);
+        haveV2 = unitise(vsub(d, vscale(coefficient, n)), v2);
+    }
+
+    if (act & ACT_REFRACT) { // Sphere.refract (Sphere.fs:108-146)
+        double index = inside ? 1.0 / ior : ior / 1.0;
+        if (!haveV2) { // parallel to the normal: straight through (re-normalised, Sphere.fs:121-124)
+            V3 nd;
+            if (unitise(d, nd)) { o = strike; d = nd; }
+        } else {
+            double sinI = sqrt(1.0 - cosI * cosI);
+            double sinO = sinI / index;
+            if (fcmp(sinO, 1.0) == CMP_GT) act |= ACT_REFLECT; // total internal reflection (Sphere.fs:130-132)
+            else {
+                double cosO = sqrt(1.0 - sinO * sinO);
+                V3 outP = walk(walk(strike, n, (-cosO)), v2, sinO);
+                V3 nd;
+                if (unitise(vsub(outP, strike), nd)) { o = strike; d = nd; }
+            }
+        }
+    }
+
+    if (act & ACT_REFLECT) { // Sphere.reflectWithoutFuzz (Sphere.fs:68-87) / InfinitePlane.pureOutgoing (InfinitePlane.fs:18-38)
+        if (!haveV2) { // directly along the normal: flip
+            d = vscale(-1.0, d);
+            o = strike;
+        } else {
+            double nC = -dot(n, d);
+            double tC = dot(v2, d);
+            V3 dest = walk(walk(strike, n, nC), v2, tC);
+            V3 nd;
+            bool ok = unitise(vsub(dest, strike), nd);
+            if (ok) d = nd;
+            if (ok || isPlane) o = strike; // a failed overwriteWithMake leaves a sphere's ray untouched (Ray.fs:14-15)
+        }
+    }
+
+    if (act & ACT_FUZZ) { // Sphere.addFuzz (Sphere.fs:89-104) / InfinitePlane.fs:63-71
+        for (;;) {
+            V3 offset = random_unit(rng);
+            V3 centre = walk(o, d, 1.0);
+            V3 target = walk(centre, offset, fuzz);
+            V3 nd;
+            if (unitise(vsub(target, strike), nd)) { o = strike; d = nd; break; }
+        }
+    }
+
+    if (act & (ACT_LAMBERT | ACT_LAMBERT_ONCE)) { // Sphere.fs:211-220 (retry) / InfinitePlane.fs:79-86 (single try)
+        V3 centre = walk(strike, n, 1.0);
+        for (;;) {
+            V3 offset = random_unit(rng);
+            V3 target = walk(centre, offset, 1.0);
+            V3 nd;
+            if (unitise(vsub(target, strike), nd)) { o = strike; d = nd; break; }
+            if (act & ACT_LAMBERT_ONCE) { colour = RTD_BLACK; return true; } // the reference throws here; see DESIGN.md
+        }
+    }
+    return false;
+}
+
+// ---- Scene.traceOnce's ray construction (Scene.fs:129-144) ---------------------------------------------------------
+struct CameraParams {
+    double eye[3], xo[3], xd[3], yd[3];
+    double vw, vh;
+    int32_t max_w, max_h;
+    int32_t spp, depth;
+};
+RTD_INLINE bool camera_ray(const CameraParams &cam, int row, int col, Rng &rng, V3 &o, V3 &d) {
+    double r1 = rng_get(rng), r2 = rng_get(rng); // GetTwo
+    double landing = (((double) col + r1) * cam.vw) / (double) cam.max_w;
+    V3 onX = walk(mk(cam.xo[0], cam.xo[1], cam.xo[2]), mk(cam.xd[0], cam.xd[1], cam.xd[2]), landing);
+    double wd = (((double) row + r2) * cam.vh) / (double) cam.max_h;
+    V3 end = walk(onX, mk(cam.yd[0], cam.yd[1], cam.yd[2]), wd);
+    o = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
+    return unitise(vsub(end, o), d);
+}
+
+// ---- Scene.traceRay (Scene.fs:93-114), whole path on one lane (unit hooks; the render kernel interleaves bounces) -------
+template <bool LDS, bool COUNT>
+RTD_INLINE uint32_t trace_ray(const SceneView<LDS> &sc, int maxCount, V3 o, V3 d, Rng &rng, Counters &cnt) {
+    uint32_t colour = RTD_WHITE;
+    int bounces = 0;
+    while (bounces <= maxCount) {
+        double t;
+        int obj = hit_object<LDS, COUNT>(sc, o, d, t, cnt);
+        if (obj < 0) return RTD_BLACK;
+        V3 strike = walk(o, d, t);
+        if (COUNT) cnt.refl++;
+        if (reflection<LDS>(sc, obj, strike, o, d, colour, rng)) return colour;
+        bounces = bounces + 1;
+    }
+    return RTD_HOTPINK;
+}
+
+} // namespace rtd

@@ -1,0 +1,277 @@
+// rt_render_kernel.h -- the persistent render megakernel for gfx950.
+//
+// Takes the role of Scene.render / renderPixel / traceOnce / traceRay (Scene.fs:93-236) for one shard of image rows.
+//
+// Execution model (DESIGN.md "Kernel"):
+//   * One workgroup per CU-slot, scene image staged ONCE per workgroup into LDS (<= ~140 KiB), then every WAVE is an
+//     independent worker: it pulls a work unit of `chunk` consecutive pixels from a global queue (one atomic per unit).
+//   * Inside a unit the 64 lanes are path slots.  A lane whose path ended takes the next (pixel, sample) item of the
+//     unit (wave ballot + mbcnt rank: "refill"), so lanes never idle while the unit has samples left, and a wave always
+//     runs ONE bounce for all live lanes per loop trip.
+//   * Adaptive sampling (Scene.fs:172-194) is done per unit: phase 1 traces 2k+1 samples of every pixel, splitting the
+//     byte sums at sample k+1; the wave then compares the two integer means per pixel, ballot-compacts the pixels that
+//     must continue, and phase 2 traces their remaining spp-2k-1 samples.
+//   * Per-sample colours are summed with LDS atomics into the wave's own accumulator slots; each pixel's PixelStats
+//     {Count,SumRed,SumGreen,SumBlue} is written once, as one 16-byte store per lane (coalesced), plus the mean RGB.
+//   No cross-workgroup communication exists, so no fences are needed; the queue counter is a relaxed device atomic.
+#pragma once
+#include "rt_device.h"
+
+namespace rtd {
+
+#define RTD_MAX_CHUNK 64
+
+struct RenderParams {
+    CameraParams cam;
+    SceneOffsets off;
+    const unsigned char *scene_image; // global copy of the image described by `off`
+    const TexRec *tex;
+    const uint8_t *texels;
+    uint64_t seed_key;
+    int32_t cols;                  // 2*max_w+1
+    int32_t row_first, row_stride; // image rows of this shard: row_first + i*row_stride
+    int32_t n_rows;
+    int32_t k;                     // firstTrial = min 5 (spp/2)   (Scene.fs:172)
+    int32_t chunk;                 // pixels per work unit, <= 64
+    int32_t *accum;                // [n_rows*cols][4]
+    uint8_t *rgb;                  // [n_rows*cols][3] or null
+    unsigned long long *counters;  // [8]: rays, aabb, prim, refl, samples, pixels_early
+    unsigned int *queue;           // work-unit counter, zeroed before launch
+};
+
+// Per-wave LDS scratch (in 4-byte words), P = pixels per work unit:
+//   acc  [2][P][3]  sums of slot 0 / slot 1
+//   pix  [P][4]     row, col, pixel index lo, hi
+//   live [P]        compacted pixel slots for phase 2
+#define RTD_WAVE_WORDS(P) (11u * (uint32_t) (P))
+
+// Wave-private LDS words: adds from many lanes may land on one word (same pixel), so they are ds_add_u32; the owner
+// lane later takes the sum and clears the word in one ds_wrxchg.  One wave's LDS operations execute in order.
+RTD_INLINE void lds_add(RTD_AS3 uint32_t *p, uint32_t v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+RTD_INLINE uint32_t lds_take(RTD_AS3 uint32_t *p) { return __hip_atomic_exchange(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+
+RTD_INLINE uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor((unsigned long long) v, off, 64);
+    return v;
+}
+
+template <bool LDS> RTD_INLINE SceneView<LDS> make_view(const RenderParams &p, const unsigned char *lds_base);
+template <> RTD_INLINE SceneView<true> make_view<true>(const RenderParams &p, const unsigned char *lds_base) {
+    SceneView<true> v;
+    const RTD_AS3 unsigned char *b = (const RTD_AS3 unsigned char *) lds_base;
+    v.box = (Ptrs<true>::d2p) (b + p.off.box);
+    v.link = (Ptrs<true>::i2p) (b + p.off.link);
+    v.geo = (Ptrs<true>::d2p) (b + p.off.geo);
+    v.meta = (Ptrs<true>::i2p) (b + p.off.meta);
+    v.mat = (Ptrs<true>::dp) (b + p.off.mat);
+    v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
+    v.tex = p.tex; v.texels = p.texels;
+    return v;
+}
+template <> RTD_INLINE SceneView<false> make_view<false>(const RenderParams &p, const unsigned char *) {
+    SceneView<false> v;
+    const unsigned char *b = p.scene_image;
+    v.box = (const d2 *) (b + p.off.box);
+    v.link = (const i2 *) (b + p.off.link);
+    v.geo = (const d2 *) (b + p.off.geo);
+    v.meta = (const i2 *) (b + p.off.meta);
+    v.mat = (const double *) (b + p.off.mat);
+    v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
+    v.tex = p.tex; v.texels = p.texels;
+    return v;
+}
+
+// Trace `total` items of the current unit.  Item i belongs to pixel slot map[i / per] (or i / per when map is null)
+// and is sample s_base + i % per of that pixel; its colour is added to accumulator slot (sample < split ? 0 : 1).
+template <bool LDS, bool COUNT>
+RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_AS3 uint32_t *acc, const RTD_AS3 uint32_t *pix,
+                          const RTD_AS3 uint32_t *live, bool use_live, uint32_t total, uint32_t per, uint32_t s_base,
+                          uint32_t split, Counters &cnt) {
+    bool alive = false;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
+    Rng rng; rng.x = rng.y = rng.z = rng.w = 0;
+    uint32_t colour = 0, slotOff = 0;
+    int bounces = 0;
+    uint32_t next = 0; // wave-uniform
+    for (;;) {
+        // ---- refill: idle lanes take the next items of the unit ----
+        unsigned long long need = __ballot(!alive);
+        if (need != 0ull && next < total) {
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) need, 0u));
+            uint32_t item = next + rank;
+            if (!alive && item < total) {
+                uint32_t j = item / per;
+                uint32_t s = s_base + (item - j * per);
+                uint32_t slot = use_live ? live[j] : j;
+                int row = (int) pix[slot * 4 + 0], col = (int) pix[slot * 4 + 1];
+                uint64_t pixel = (uint64_t) pix[slot * 4 + 2] | ((uint64_t) pix[slot * 4 + 3] << 32);
+                rng = stream_for(p.seed_key, pixel, s);
+                slotOff = ((s < split) ? 0u : (uint32_t) p.chunk * 3u) + slot * 3u;
+                colour = RTD_WHITE;
+                bounces = 0;
+                if (camera_ray(p.cam, row, col, rng, o, d)) alive = true;
+                // else: Scene.fs:144's ValueOption.get would throw; the sample counts as Black (adds nothing)
+            }
+            next += (uint32_t) __popcll(need);
+            next = __builtin_amdgcn_readfirstlane(next);
+        }
+        if (__ballot(alive) == 0ull) {
+            if (next >= total) break;
+            continue;
+        }
+        // ---- one bounce of Scene.traceRay (Scene.fs:98-112) for every live lane ----
+        if (alive) {
+            double t;
+            int obj = hit_object<LDS, COUNT>(sc, o, d, t, cnt);
+            bool done = false;
+            uint32_t result = RTD_BLACK;
+            if (obj < 0) done = true; // "never heard from again": Black
+            else {
+                V3 strike = walk(o, d, t); // Ray.walkAlong ray bestLength (Scene.fs:91)
+                if (COUNT) cnt.refl++;
+                if (reflection<LDS>(sc, obj, strike, o, d, colour, rng)) { done = true; result = colour; }
+                else {
+                    bounces = bounces + 1;
+                    if (bounces > p.cam.depth) { done = true; result = RTD_HOTPINK; } // Scene.fs:98,114
+                }
+            }
+            if (done) {
+                if (result != 0u) { // PixelStats.add (Pixel.fs:97-101); Count is implied by the item count
+                    lds_add(acc + slotOff + 0, result & 0xFFu);
+                    lds_add(acc + slotOff + 1, (result >> 8) & 0xFFu);
+                    lds_add(acc + slotOff + 2, (result >> 16) & 0xFFu);
+                }
+                alive = false;
+            }
+        }
+    }
+}
+
+template <bool LDS, bool COUNT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    uint32_t sceneBytes = 0;
+    if (LDS) { // stage the scene image: 16 B per lane per trip, coalesced
+        sceneBytes = p.off.total;
+        const d2 *src = (const d2 *) p.scene_image;
+        RTD_AS3 d2 *dst = (RTD_AS3 d2 *) smem;
+        for (uint32_t i = threadIdx.x; i < sceneBytes / 16u; i += BLOCK) dst[i] = src[i];
+        __syncthreads();
+    }
+    const SceneView<LDS> sc = make_view<LDS>(p, smem);
+    const uint32_t P = (uint32_t) p.chunk;
+    RTD_AS3 uint32_t *wv = (RTD_AS3 uint32_t *) (smem + sceneBytes) + (size_t) wave * RTD_WAVE_WORDS(P);
+    RTD_AS3 uint32_t *acc = wv;
+    RTD_AS3 uint32_t *pix = wv + 6u * P;
+    RTD_AS3 uint32_t *live = pix + 4u * P;
+
+    const uint64_t nLocal = (uint64_t) p.n_rows * (uint64_t) p.cols;
+    const uint32_t k = (uint32_t) p.k;
+    const uint32_t n1 = 2u * k + 1u;
+    const int n2s = p.cam.spp - 2 * p.k - 1; // Scene.fs:191
+    const uint32_t n2 = n2s > 0 ? (uint32_t) n2s : 0u;
+
+    Counters cnt; cnt.rays = cnt.aabb = cnt.prim = cnt.refl = 0;
+    uint32_t earlyCount = 0;
+    uint64_t sampleCount = 0; // Scene.traceOnce calls = sum of PixelStats.Count
+
+    for (;;) {
+        uint32_t unit = 0;
+        if (lane == 0) unit = atomicAdd(p.queue, 1u);
+        unit = __builtin_amdgcn_readfirstlane(unit);
+        const uint64_t first = (uint64_t) unit * P;
+        if (first >= nLocal) break;
+        const uint32_t npx = (uint32_t) ((nLocal - first < (uint64_t) P) ? (nLocal - first) : (uint64_t) P);
+
+        // per-pixel coordinates (Scene.fs:219,226) and stream key; clear the accumulators
+        for (uint32_t i = (uint32_t) lane; i < 6u * P; i += 64u) acc[i] = 0u;
+        if ((uint32_t) lane < npx) {
+            uint64_t lp = first + (uint32_t) lane;
+            uint32_t lr = (uint32_t) (lp / (uint64_t) p.cols);
+            uint32_t c = (uint32_t) (lp - (uint64_t) lr * (uint64_t) p.cols);
+            uint32_t r = (uint32_t) p.row_first + lr * (uint32_t) p.row_stride;
+            uint64_t pixel = (uint64_t) r * (uint64_t) p.cols + c;
+            pix[lane * 4 + 0] = (uint32_t) (p.cam.max_h - (int) r - 1);
+            pix[lane * 4 + 1] = (uint32_t) ((int) c - p.cam.max_w);
+            pix[lane * 4 + 2] = (uint32_t) pixel;
+            pix[lane * 4 + 3] = (uint32_t) (pixel >> 32);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- phase 1: 2k+1 samples per pixel, sums split after sample k (Scene.fs:172-182) ----
+        run_items<LDS, COUNT>(p, sc, acc, pix, live, false, npx * n1, n1, 0u, k + 1u, cnt);
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- decide (Scene.fs:177-188) and compact the pixels that continue ----
+        int sumR = 0, sumG = 0, sumB = 0, count = 0;
+        bool cont = false;
+        if ((uint32_t) lane < npx) {
+            int aR = (int) lds_take(acc + lane * 3 + 0), aG = (int) lds_take(acc + lane * 3 + 1), aB = (int) lds_take(acc + lane * 3 + 2);
+            int bR = (int) lds_take(acc + P * 3 + lane * 3 + 0), bG = (int) lds_take(acc + P * 3 + lane * 3 + 1),
+                bB = (int) lds_take(acc + P * 3 + lane * 3 + 2);
+            int c1 = (int) k + 1;
+            count = (int) n1;
+            sumR = aR + bR; sumG = aG + bG; sumB = aB + bB;
+            // PixelStats.mean (Pixel.fs:103-108) is integer division; Pixel.difference (Pixel.fs:113-116) is L1
+            int oR = (aR / c1) & 0xFF, oG = (aG / c1) & 0xFF, oB = (aB / c1) & 0xFF;
+            int nR = (sumR / count) & 0xFF, nG = (sumG / count) & 0xFF, nB = (sumB / count) & 0xFF;
+            int diff = abs(nR - oR) + abs(nG - oG) + abs(nB - oB);
+            if (diff == 0) earlyCount++;
+            cont = (diff != 0) && (n2 > 0u);
+        }
+        unsigned long long liveMask = __ballot(cont);
+        uint32_t nLive = (uint32_t) __popcll(liveMask);
+        if (cont) {
+            uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (liveMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) liveMask, 0u));
+            live[pos] = (uint32_t) lane;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- phase 2: the remaining spp-2k-1 samples of the surviving pixels (Scene.fs:191-192) ----
+        if (nLive > 0u) {
+            run_items<LDS, COUNT>(p, sc, acc, pix, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt);
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ---- PixelStats and mean out: one 16-byte store per pixel ----
+        if ((uint32_t) lane < npx) {
+            if (cont) {
+                sumR += (int) lds_take(acc + lane * 3 + 0);
+                sumG += (int) lds_take(acc + lane * 3 + 1);
+                sumB += (int) lds_take(acc + lane * 3 + 2);
+                count += (int) n2;
+            }
+            uint64_t lp = first + (uint32_t) lane;
+            sampleCount += (uint64_t) count;
+            i4 out; out.x = count; out.y = sumR; out.z = sumG; out.w = sumB;
+            ((i4 *) p.accum)[lp] = out;
+            if (p.rgb) {
+                p.rgb[lp * 3 + 0] = (uint8_t) (sumR / count);
+                p.rgb[lp * 3 + 1] = (uint8_t) (sumG / count);
+                p.rgb[lp * 3 + 2] = (uint8_t) (sumB / count);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- counters: one wave reduction and <= 6 atomics per wave per launch ----
+    uint64_t e = wave_sum_u64(earlyCount), s = wave_sum_u64(sampleCount);
+    if (COUNT) {
+        uint64_t a = wave_sum_u64(cnt.rays), b = wave_sum_u64(cnt.aabb), c = wave_sum_u64(cnt.prim), dd = wave_sum_u64(cnt.refl);
+        if (lane == 0) {
+            atomicAdd(&p.counters[0], (unsigned long long) a);
+            atomicAdd(&p.counters[1], (unsigned long long) b);
+            atomicAdd(&p.counters[2], (unsigned long long) c);
+            atomicAdd(&p.counters[3], (unsigned long long) dd);
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&p.counters[4], (unsigned long long) s);
+        atomicAdd(&p.counters[5], (unsigned long long) e);
+    }
+}
+
+} // namespace rtd

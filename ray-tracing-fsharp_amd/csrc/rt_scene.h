@@ -1,0 +1,316 @@
+// rt_scene.h -- host side of Scene.make (Scene.fs:15-28): partition, BoundingBoxTree.make (BoundingBoxTree.fs:9-43),
+// and the flattening of both into the device image described in rt_device.h.  Host-only C++ (no HIP calls here).
+//
+// The tree is built as index arrays straight into pre-order (node, left subtree, right subtree) with a skip link per
+// node, which is the layout the stackless device walk needs; no pointer tree is ever materialised.
+#pragma once
+#include "../../include/rtfs_amd.h"
+#include "rt_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace rth {
+
+struct Box { double mn[3], mx[3]; };
+
+// BoundingBox.mergeTwo (BoundingBox.fs:96-108)
+static inline Box merge_two(const Box &i, const Box &j) {
+    Box o;
+    for (int a = 0; a < 3; ++a) {
+        o.mn[a] = i.mn[a] < j.mn[a] ? i.mn[a] : j.mn[a];
+        o.mx[a] = i.mx[a] < j.mx[a] ? j.mx[a] : i.mx[a];
+    }
+    return o;
+}
+// BoundingBox.volume (BoundingBox.fs:13-16)
+static inline double volume(const Box &b) { return (b.mx[0] - b.mn[0]) * (b.mx[1] - b.mn[1]) * (b.mx[2] - b.mn[2]); }
+
+struct FlatTree {
+    std::vector<int32_t> skip, prim; // prim = object-table index of a Leaf, -1 for a Branch
+    std::vector<Box> box;
+    int depth = 0;
+};
+
+class TreeBuilder {
+  public:
+    TreeBuilder(const std::vector<Box> &objBoxes, FlatTree &out) : ob(objBoxes), t(out) {}
+
+    // BoundingBoxTree.make's `go` (BoundingBoxTree.fs:14-41) over object indices `ids`
+    void go(const std::vector<int32_t> &ids, int depth) {
+        if (depth > t.depth) t.depth = depth;
+        const size_t me = emit(merge_all(ids), -1);
+        if (ids.size() == 1) { // Leaf boxes.[0]
+            t.prim[me] = ids[0];
+            t.box[me] = ob[(size_t) ids[0]];
+        } else if (ids.size() == 2) { // Branch (Leaf boxes.[0], Leaf boxes.[1], boundAll)
+            leaf(ids[0], depth + 1);
+            leaf(ids[1], depth + 1);
+        } else {
+            std::vector<int32_t> bestL, bestR;
+            double bestCost = 0.0;
+            for (int axis = 0; axis < 3; ++axis) {
+                // Array.sortBy on Min[axis] (BoundingBoxTree.fs:23); .NET's sort is unstable, so equal keys have no defined
+                // order in the reference -- defined here as stable (DESIGN.md "Tree shape").
+                std::vector<int32_t> sorted = ids;
+                std::stable_sort(sorted.begin(), sorted.end(),
+                                 [&](int32_t a, int32_t b) { return ob[(size_t) a].mn[axis] < ob[(size_t) b].mn[axis]; });
+                const size_t half = sorted.size() / 2;
+                std::vector<int32_t> l(sorted.begin(), sorted.begin() + (long) half + 1); // boxes.[0 .. n/2]
+                std::vector<int32_t> r(sorted.begin() + (long) half + 1, sorted.end());   // boxes.[n/2+1 ..]
+                const double cost = volume(merge_all(l)) + volume(merge_all(r));
+                if (axis == 0 || cost < bestCost) { bestCost = cost; bestL.swap(l); bestR.swap(r); } // Array.minBy: first minimum
+            }
+            go(bestL, depth + 1);
+            go(bestR, depth + 1);
+        }
+        t.skip[me] = (int32_t) t.skip.size();
+    }
+
+  private:
+    const std::vector<Box> &ob;
+    FlatTree &t;
+    Box merge_all(const std::vector<int32_t> &ids) const { // BoundingBox.merge = Array.reduce mergeTwo
+        Box acc = ob[(size_t) ids[0]];
+        for (size_t i = 1; i < ids.size(); ++i) acc = merge_two(acc, ob[(size_t) ids[i]]);
+        return acc;
+    }
+    size_t emit(const Box &b, int32_t prim) {
+        t.skip.push_back(0);
+        t.prim.push_back(prim);
+        t.box.push_back(b);
+        return t.skip.size() - 1;
+    }
+    void leaf(int32_t id, int depth) {
+        if (depth > t.depth) t.depth = depth;
+        const size_t me = emit(ob[(size_t) id], id);
+        t.skip[me] = (int32_t) t.skip.size();
+    }
+};
+
+struct HostScene {
+    std::vector<rt_hittable> hittables;
+    std::vector<rt_texture> textures;
+    std::vector<rtd::TexRec> texRecs;
+    std::vector<uint8_t> texelBlob;
+    std::vector<int32_t> objToOrig; // object-table index -> index in `hittables`
+    std::vector<int32_t> origToObj;
+    FlatTree tree;
+    std::vector<unsigned char> image;
+    rtd::SceneOffsets off{};
+};
+
+static inline uint32_t pack_rgb(const uint8_t rgb[3]) { return (uint32_t) rgb[0] | ((uint32_t) rgb[1] << 8) | ((uint32_t) rgb[2] << 16); }
+
+static inline size_t align16(size_t v) { return (v + 15u) & ~(size_t) 15u; }
+
+// Returns an empty string on success, otherwise the message for rt_last_error().
+static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture *tex, size_t ntex, HostScene &s, int &status) {
+    status = RT_ERR_INVALID_ARGUMENT;
+    if (n > 0 && !h) return "hittables is NULL";
+    if (ntex > 0 && !tex) return "textures is NULL";
+    if (ntex > 254) { status = RT_ERR_UNSUPPORTED; return "at most 254 textures"; }
+    s.hittables.assign(h, h + n);
+    s.textures.assign(tex, tex + ntex);
+
+    // ---- textures ----
+    s.texRecs.resize(ntex);
+    for (size_t i = 0; i < ntex; ++i) {
+        const rt_texture &t = tex[i];
+        rtd::TexRec r{};
+        r.kind = t.kind;
+        r.rgb = pack_rgb(t.rgb);
+        r.ramp = (uint32_t) t.ramp_src[0] | ((uint32_t) t.ramp_src[1] << 8) | ((uint32_t) t.ramp_src[2] << 16);
+        r.even = t.even; r.odd = t.odd;
+        r.width = t.width; r.height = t.height;
+        r.grid = t.grid_size;
+        r.cx = t.map_centre[0]; r.cy = t.map_centre[1]; r.cz = t.map_centre[2];
+        r.map_radius = t.map_radius;
+        switch (t.kind) {
+        case RT_TEXTURE_COLOUR: break;
+        case RT_TEXTURE_UV_RAMP:
+            for (int k = 0; k < 3; ++k) if (t.ramp_src[k] > RT_RAMP_V) return "texture " + std::to_string(i) + ": bad ramp source";
+            break;
+        case RT_TEXTURE_CHECKERED:
+            if (t.even < 0 || t.odd < 0 || (size_t) t.even >= i || (size_t) t.odd >= i)
+                return "texture " + std::to_string(i) + ": Checkered children must have smaller indices";
+            break;
+        case RT_TEXTURE_IMAGE: {
+            if (!t.texels || t.width <= 0 || t.height <= 0) return "texture " + std::to_string(i) + ": image without texels";
+            const size_t bytes = (size_t) t.width * (size_t) t.height * 3u;
+            r.texel_off = (uint32_t) s.texelBlob.size();
+            s.texelBlob.insert(s.texelBlob.end(), t.texels, t.texels + bytes);
+            while (s.texelBlob.size() % 16u) s.texelBlob.push_back(0);
+            break;
+        }
+        default: status = RT_ERR_UNSUPPORTED; return "texture " + std::to_string(i) + ": Texture.Arbitrary closures cannot cross the C ABI";
+        }
+        s.texRecs[i] = r;
+        s.textures[i].texels = nullptr; // not owned
+    }
+
+    // ---- Scene.make: Array.partition (snd >> ValueOption.isSome), order kept on both sides (Scene.fs:16-22) ----
+    std::vector<int32_t> bounded, unbounded;
+    for (size_t i = 0; i < n; ++i) {
+        const rt_hittable &o = h[i];
+        if (o.kind > RT_HITTABLE_INFINITE_PLANE) return "hittable " + std::to_string(i) + ": bad kind";
+        const bool plane = o.kind == RT_HITTABLE_INFINITE_PLANE;
+        if (plane ? o.style > RT_PLANE_FUZZED_REFLECTION : o.style > RT_SPHERE_GLASS) return "hittable " + std::to_string(i) + ": bad style";
+        if (o.texture >= (int32_t) ntex) return "hittable " + std::to_string(i) + ": texture index out of range";
+        if (o.texture >= 0) {
+            const bool carries = plane ? o.style == RT_PLANE_LIGHT_SOURCE : o.style != RT_SPHERE_LIGHT_SOURCE_CAP;
+            if (!carries) return "hittable " + std::to_string(i) + ": this style carries a Pixel, not a Texture";
+        }
+        (o.kind == RT_HITTABLE_SPHERE ? bounded : unbounded).push_back((int32_t) i);
+    }
+    const size_t nb = bounded.size(), nu = unbounded.size(), nobj = nb + nu;
+    s.objToOrig.clear();
+    s.objToOrig.insert(s.objToOrig.end(), bounded.begin(), bounded.end());
+    s.objToOrig.insert(s.objToOrig.end(), unbounded.begin(), unbounded.end());
+    s.origToObj.assign(n, -1);
+    for (size_t j = 0; j < nobj; ++j) s.origToObj[(size_t) s.objToOrig[j]] = (int32_t) j;
+
+    // ---- Sphere.make's box (Sphere.fs:333-336): centre + (-r,-r,-r) .. centre + (r,r,r); inverted when r < 0 ----
+    std::vector<Box> boxes(nb);
+    for (size_t j = 0; j < nb; ++j) {
+        const rt_hittable &o = h[(size_t) bounded[j]];
+        for (int a = 0; a < 3; ++a) {
+            boxes[j].mn[a] = o.point[a] + (-o.radius);
+            boxes[j].mx[a] = o.point[a] + o.radius;
+        }
+    }
+    s.tree = FlatTree{};
+    if (nb > 0) {
+        std::vector<int32_t> ids(nb);
+        for (size_t j = 0; j < nb; ++j) ids[j] = (int32_t) j;
+        TreeBuilder(boxes, s.tree).go(ids, 1);
+    }
+    const size_t nn = s.tree.skip.size();
+
+    // ---- device image ----
+    rtd::SceneOffsets &off = s.off;
+    size_t cur = 0;
+    off.box = (uint32_t) cur;  cur = align16(cur + nn * 48u);
+    off.link = (uint32_t) cur; cur = align16(cur + nn * 8u);
+    off.geo = (uint32_t) cur;  cur = align16(cur + nobj * 48u);
+    off.meta = (uint32_t) cur; cur = align16(cur + nobj * 8u);
+    off.mat = (uint32_t) cur;  cur = align16(cur + nobj * 24u);
+    off.total = (uint32_t) cur;
+    off.n_nodes = (int32_t) nn; off.n_bounded = (int32_t) nb; off.n_unbounded = (int32_t) nu;
+    s.image.assign(cur == 0 ? 16 : cur, 0);
+    if (cur == 0) off.total = 16;
+    double *pbox = (double *) (s.image.data() + off.box);
+    int32_t *plink = (int32_t *) (s.image.data() + off.link);
+    double *pgeo = (double *) (s.image.data() + off.geo);
+    int32_t *pmeta = (int32_t *) (s.image.data() + off.meta);
+    double *pmat = (double *) (s.image.data() + off.mat);
+    for (size_t i = 0; i < nn; ++i) {
+        for (int a = 0; a < 3; ++a) { pbox[i * 6 + (size_t) a * 2] = s.tree.box[i].mn[a]; pbox[i * 6 + (size_t) a * 2 + 1] = s.tree.box[i].mx[a]; }
+        plink[i * 2] = s.tree.skip[i];
+        plink[i * 2 + 1] = s.tree.prim[i];
+    }
+    for (size_t j = 0; j < nobj; ++j) {
+        const rt_hittable &o = h[(size_t) s.objToOrig[j]];
+        double *g = pgeo + j * 6;
+        uint32_t m0;
+        if (o.kind == RT_HITTABLE_INFINITE_PLANE) {
+            g[0] = o.point[0]; g[1] = o.point[1]; g[2] = o.point[2];
+            g[3] = o.normal[0]; g[4] = o.normal[1]; g[5] = o.normal[2];
+            m0 = RTD_KIND_PLANE | (o.style << 2);
+            pmat[j * 3 + 0] = o.albedo; pmat[j * 3 + 1] = o.fuzz; pmat[j * 3 + 2] = 0.0;
+        } else {
+            g[0] = o.point[0]; g[1] = o.point[1]; g[2] = o.point[2];
+            g[3] = o.radius * o.radius; // RadiusSquared (Sphere.fs:326)
+            g[4] = o.radius; g[5] = 0.0;
+            // flipped = Float.compare this.Radius 0.0 = Less (Sphere.fs:321)
+            const bool flipped = !(std::fabs(o.radius - 0.0) < 0.00000001) && (o.radius < 0.0);
+            m0 = RTD_KIND_SPHERE | (o.style << 2) | (flipped ? 32u : 0u);
+            const bool usesIor = o.style == RT_SPHERE_DIELECTRIC || o.style == RT_SPHERE_GLASS;
+            pmat[j * 3 + 0] = o.albedo; pmat[j * 3 + 1] = usesIor ? o.ior : o.fuzz; pmat[j * 3 + 2] = o.prob;
+        }
+        pmeta[j * 2] = (int32_t) m0;
+        pmeta[j * 2 + 1] = (int32_t) (pack_rgb(o.rgb) | ((uint32_t) (o.texture + 1) << 24));
+    }
+    status = RT_OK;
+    return std::string();
+}
+
+// ---- Camera.makeBasic (Camera.fs:34-59) with Plane.makeNormalTo' (Plane.fs:22-38) and Plane.basis (Plane.fs:82-97) ----
+struct H3 { double x, y, z; };
+static inline double hdot(H3 a, H3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline H3 hscale(double s, H3 v) { return H3{s * v.x, s * v.y, s * v.z}; }
+static inline H3 hsum(H3 a, H3 b) { return H3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline bool hunit(H3 v, H3 &out) { // Vector.unitise (Point.fs:28-35)
+    double d = hdot(v, v);
+    if (std::fabs(d - 0.0) < 0.00000001) return false;
+    double f = 1.0 / std::sqrt(d);
+    out = hscale(f, v);
+    return true;
+}
+static inline H3 hcross(H3 p, H3 q) { return H3{p.y * q.z - p.z * q.y, p.z * q.x - p.x * q.z, p.x * q.y - q.x * p.y}; } // Point.fs:44-45
+
+static bool camera_make_basic(int32_t spp, double focal, double aspect, const double origin[3], const double dir[3], const double up[3],
+                              rt_camera *out) {
+    const H3 o{origin[0], origin[1], origin[2]}, v{dir[0], dir[1], dir[2]};
+    const H3 corner{o.x + (v.x * focal), o.y + (v.y * focal), o.z + (v.z * focal)}; // Ray.walkAlong view focalLength
+    // Plane.makeNormalTo (Plane.fs:22-36)
+    H3 v1 = (std::fabs(v.z - 0.0) < 0.00000001) ? H3{0.0, 0.0, 1.0} : H3{1.0, 1.0, ((-v.x - v.y) / v.z)};
+    H3 v2, v1u, upu;
+    if (!hunit(hcross(v, v1), v2) || !hunit(v1, v1u)) return false; // ValueOption.get
+    // Plane.basis viewUp (Plane.fs:82-97)
+    if (!hunit(H3{up[0], up[1], up[2]}, upu)) return false;
+    const double c1 = hdot(v1u, upu), c2 = hdot(v2, upu);
+    H3 yAxis, xAxis;
+    if (!hunit(hsum(hscale(c1, v1u), hscale(c2, v2)), yAxis)) return false;
+    if (!hunit(hsum(hscale(c2, v1u), hscale(-c1, v2)), xAxis)) return false;
+    auto st = [](double *d, H3 a) { d[0] = a.x; d[1] = a.y; d[2] = a.z; };
+    st(out->view_origin, o); st(out->view_dir, v);
+    st(out->xaxis_origin, corner); st(out->xaxis_dir, xAxis);
+    st(out->yaxis_origin, corner); st(out->yaxis_dir, yAxis);
+    out->viewport_height = 2.0;
+    out->viewport_width = aspect * 2.0;
+    out->focal_length = focal;
+    out->samples_per_pixel = spp;
+    out->bounce_depth = 150; // Camera.fs:58
+    return true;
+}
+
+// ---- PixelOutput.correct (ImageOutput.fs:11-18) and ImageOutput.writePpm (ImageOutput.fs:163-197) ----
+static inline uint8_t gamma_correct(uint8_t b) {
+    int i = (int) std::rint(std::sqrt((double) b / 255.0) * 255.0);
+    if (i == 256) i = 255;
+    return (uint8_t) i;
+}
+
+static inline void append_uint(std::string &s, unsigned v) {
+    char buf[12];
+    int n = 0;
+    do { buf[n++] = (char) ('0' + v % 10u); v /= 10u; } while (v);
+    while (n) s.push_back(buf[--n]);
+}
+
+static std::string format_ppm(const uint8_t *rgb, int32_t rows, int32_t cols, bool gamma) {
+    uint8_t lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = gamma ? gamma_correct((uint8_t) i) : (uint8_t) i;
+    std::string s;
+    s.reserve((size_t) rows * (size_t) cols * 12u + 32u);
+    s += "P3\n";
+    append_uint(s, (unsigned) cols); s.push_back(' '); append_uint(s, (unsigned) rows); s.push_back('\n');
+    s += "255\n";
+    for (int32_t r = 0; r < rows; ++r) {
+        for (int32_t c = 0; c < cols; ++c) {
+            const uint8_t *p = rgb + ((size_t) r * (size_t) cols + (size_t) c) * 3u;
+            append_uint(s, lut[p[0]]); s.push_back(' ');
+            append_uint(s, lut[p[1]]); s.push_back(' ');
+            append_uint(s, lut[p[2]]);
+            if (c != cols - 1) s.push_back(' ');
+        }
+        if (r != rows - 1) s.push_back('\n'); // no trailing newline (ImageOutput.fs:191-196)
+    }
+    return s;
+}
+
+} // namespace rth

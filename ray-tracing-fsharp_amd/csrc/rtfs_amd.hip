@@ -1,0 +1,706 @@
+// rtfs_amd.hip -- C ABI entry points of librtfs_amd.so (declared in include/rtfs_amd.h).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see Makefile).
+// There is NO CPU fallback: every compute entry point returns RT_ERR_NO_DEVICE when no HIP device is visible.
+#include "../../include/rtfs_amd.h"
+#include "rt_device.h"
+#include "rt_render_kernel.h"
+#include "rt_scene.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace rtd;
+
+// ------------------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                                                   \
+    do {                                                                                                                \
+        hipError_t e_ = (expr);                                                                                         \
+        if (e_ != hipSuccess) return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+
+static int visible_devices() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); return 0; }
+    return n;
+}
+static int need_device(int device) {
+    const int n = visible_devices();
+    if (n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible: the render path has no CPU fallback");
+    if (device < 0 || device >= n) return fail(RT_ERR_INVALID_ARGUMENT, "device index out of range");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// scene handle: host image + lazily created per-device copies
+// ------------------------------------------------------------------------------------------------------------
+struct DeviceScene {
+    unsigned char *image = nullptr;
+    TexRec *tex = nullptr;
+    uint8_t *texels = nullptr;
+    unsigned char *scratch = nullptr; // ring of 128-byte {counters[8], queue} slots
+    unsigned next_slot = 0;
+    int cu_count = 0;
+};
+#define RT_SCRATCH_SLOTS 64
+#define RT_SCRATCH_BYTES 128
+
+struct rt_scene {
+    rth::HostScene host;
+    std::map<int, DeviceScene> dev;
+    std::mutex mu;
+};
+
+static int g_block_threads = 0, g_chunk_pixels = 0, g_blocks_per_cu = 0;
+
+static int device_scene(rt_scene *s, int device, DeviceScene **out) {
+    std::lock_guard<std::mutex> lock(s->mu);
+    auto it = s->dev.find(device);
+    if (it != s->dev.end()) { *out = &it->second; return RT_OK; }
+    DeviceScene d;
+    const rth::HostScene &h = s->host;
+    HIP_TRY(hipMalloc((void **) &d.image, h.image.size()));
+    HIP_TRY(hipMemcpy(d.image, h.image.data(), h.image.size(), hipMemcpyHostToDevice));
+    if (!h.texRecs.empty()) {
+        HIP_TRY(hipMalloc((void **) &d.tex, h.texRecs.size() * sizeof(TexRec)));
+        HIP_TRY(hipMemcpy(d.tex, h.texRecs.data(), h.texRecs.size() * sizeof(TexRec), hipMemcpyHostToDevice));
+    }
+    if (!h.texelBlob.empty()) {
+        HIP_TRY(hipMalloc((void **) &d.texels, h.texelBlob.size()));
+        HIP_TRY(hipMemcpy(d.texels, h.texelBlob.data(), h.texelBlob.size(), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc((void **) &d.scratch, RT_SCRATCH_SLOTS * RT_SCRATCH_BYTES));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    d.cu_count = prop.multiProcessorCount;
+    auto ins = s->dev.emplace(device, d);
+    *out = &ins.first->second;
+    return RT_OK;
+}
+
+// LDS budget: 160 KiB per CU (MI355X_MICROARCH.md); the scene image plus every wave's scratch must fit one workgroup.
+#define RT_LDS_BYTES 163840u
+static bool lds_fits(const rth::HostScene &h, int block_threads, int chunk) {
+    const uint32_t waves = (uint32_t) block_threads / 64u;
+    return (uint64_t) h.off.total + (uint64_t) waves * RTD_WAVE_WORDS(chunk) * 4u <= RT_LDS_BYTES;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// launch
+// ------------------------------------------------------------------------------------------------------------
+typedef void (*render_fn)(const RenderParams);
+static render_fn pick_kernel(bool lds, bool count, int block) {
+    if (block == 1024) {
+        if (lds) return count ? render_kernel<true, true, 1024> : render_kernel<true, false, 1024>;
+        return count ? render_kernel<false, true, 1024> : render_kernel<false, false, 1024>;
+    }
+    if (block == 512) {
+        if (lds) return count ? render_kernel<true, true, 512> : render_kernel<true, false, 512>;
+        return count ? render_kernel<false, true, 512> : render_kernel<false, false, 512>;
+    }
+    if (lds) return count ? render_kernel<true, true, 256> : render_kernel<true, false, 256>;
+    return count ? render_kernel<false, true, 256> : render_kernel<false, false, 256>;
+}
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+const char *rt_last_error(void) { return g_err.c_str(); }
+int rt_device_count(void) { return visible_devices(); }
+
+size_t rt_abi_sizeof(int which) {
+    switch (which) {
+    case 0: return sizeof(rt_hittable);
+    case 1: return sizeof(rt_texture);
+    case 2: return sizeof(rt_camera);
+    case 3: return sizeof(rt_scene_info);
+    case 4: return sizeof(rt_stats);
+    default: return 0;
+    }
+}
+
+int rt_set_launch_config(int32_t block_threads, int32_t chunk_pixels, int32_t blocks_per_cu) {
+    if (block_threads != 0 && block_threads != 256 && block_threads != 512 && block_threads != 1024)
+        return fail(RT_ERR_INVALID_ARGUMENT, "block_threads must be 0, 256, 512 or 1024");
+    if (chunk_pixels < 0 || chunk_pixels > RTD_MAX_CHUNK) return fail(RT_ERR_INVALID_ARGUMENT, "chunk_pixels must be in [0, 64]");
+    if (blocks_per_cu < 0 || blocks_per_cu > 8) return fail(RT_ERR_INVALID_ARGUMENT, "blocks_per_cu must be in [0, 8]");
+    g_block_threads = block_threads;
+    g_chunk_pixels = chunk_pixels;
+    g_blocks_per_cu = blocks_per_cu;
+    return RT_OK;
+}
+
+int rt_camera_make_basic(int32_t spp, double focal, double aspect, const double origin[3], const double view_direction[3],
+                         const double view_up[3], rt_camera *out) {
+    if (!origin || !view_direction || !view_up || !out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!rth::camera_make_basic(spp, focal, aspect, origin, view_direction, view_up, out))
+        return fail(RT_ERR_INVALID_ARGUMENT, "degenerate camera frame (the reference's ValueOption.get would throw)");
+    return RT_OK;
+}
+
+int rt_scene_create(const rt_hittable *hittables, size_t n_hittables, const rt_texture *textures, size_t n_textures, rt_scene **out) {
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
+    std::unique_ptr<rt_scene> s(new rt_scene());
+    int status = RT_OK;
+    std::string msg = rth::build_scene(hittables, n_hittables, textures, n_textures, s->host, status);
+    if (status != RT_OK) return fail(status, msg);
+    *out = s.release();
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene *s) {
+    if (!s) return;
+    for (auto &kv : s->dev) {
+        if (hipSetDevice(kv.first) != hipSuccess) continue;
+        (void) hipFree(kv.second.image);
+        (void) hipFree(kv.second.tex);
+        (void) hipFree(kv.second.texels);
+        (void) hipFree(kv.second.scratch);
+    }
+    delete s;
+}
+
+int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
+    if (!s || !out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    const rth::HostScene &h = s->host;
+    out->n_bounded = h.off.n_bounded;
+    out->n_unbounded = h.off.n_unbounded;
+    out->n_nodes = h.off.n_nodes;
+    out->tree_depth = h.tree.depth;
+    out->n_textures = (int32_t) h.texRecs.size();
+    out->lds_resident = lds_fits(h, g_block_threads ? g_block_threads : 512, g_chunk_pixels ? g_chunk_pixels : 32) ? 1 : 0;
+    out->scene_bytes = (int64_t) h.off.total;
+    out->texel_bytes = (int64_t) h.texelBlob.size();
+    return RT_OK;
+}
+
+int rt_scene_get_tree(const rt_scene *s, int32_t *skip, int32_t *prim, double *boxes) {
+    if (!s) return fail(RT_ERR_INVALID_ARGUMENT, "NULL scene");
+    const rth::HostScene &h = s->host;
+    const size_t nn = h.tree.skip.size();
+    for (size_t i = 0; i < nn; ++i) {
+        if (skip) skip[i] = h.tree.skip[i];
+        if (prim) prim[i] = h.tree.prim[i] < 0 ? -1 : h.objToOrig[(size_t) h.tree.prim[i]];
+        if (boxes) for (int a = 0; a < 3; ++a) { boxes[i * 6 + (size_t) a * 2] = h.tree.box[i].mn[a]; boxes[i * 6 + (size_t) a * 2 + 1] = h.tree.box[i].mx[a]; }
+    }
+    return RT_OK;
+}
+
+static int check_geometry(const rt_camera *camera, int32_t max_w, int32_t max_h, int32_t row_first, int32_t row_stride, int32_t n_rows) {
+    if (!camera) return fail(RT_ERR_INVALID_ARGUMENT, "camera is NULL");
+    if (max_w <= 0 || max_h <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "max_width_coord and max_height_coord must be positive");
+    if (max_w > (1 << 20) || max_h > (1 << 20)) return fail(RT_ERR_INVALID_ARGUMENT, "image too large");
+    if (camera->samples_per_pixel < 1) return fail(RT_ERR_INVALID_ARGUMENT, "samples_per_pixel must be >= 1");
+    if (camera->samples_per_pixel > 8000000) return fail(RT_ERR_INVALID_ARGUMENT, "samples_per_pixel too large for int32 sums (255*spp)");
+    if (camera->bounce_depth < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bounce_depth must be >= 0");
+    const int rows = 2 * max_h + 1;
+    if (row_stride <= 0 || row_first < 0 || n_rows < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad row shard");
+    if (n_rows > 0 && (int64_t) row_first + (int64_t) (n_rows - 1) * row_stride >= rows) return fail(RT_ERR_INVALID_ARGUMENT, "row shard exceeds the image");
+    return RT_OK;
+}
+
+int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max_w, int32_t max_h, uint64_t seed, int32_t device,
+                     int32_t row_first, int32_t row_stride, int32_t n_rows, uint32_t flags, void *d_accum, void *d_rgb, void *stream,
+                     rt_stats *stats) {
+    if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
+    int rc = check_geometry(camera, max_w, max_h, row_first, row_stride, n_rows);
+    if (rc != RT_OK) return rc;
+    if (n_rows > 0 && !d_accum) return fail(RT_ERR_INVALID_ARGUMENT, "d_accum is NULL");
+    rc = need_device(device);
+    if (rc != RT_OK) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    DeviceScene *ds = nullptr;
+    rc = device_scene(const_cast<rt_scene *>(scene), device, &ds);
+    if (rc != RT_OK) return rc;
+    const rth::HostScene &h = scene->host;
+    hipStream_t st = (hipStream_t) stream;
+
+    int block = g_block_threads ? g_block_threads : 512;
+    int chunk = g_chunk_pixels ? g_chunk_pixels : 32;
+    const bool count = (flags & RT_RENDER_COUNTERS) != 0;
+    bool lds = lds_fits(h, block, chunk);
+    if (!lds && block > 256 && lds_fits(h, 256, chunk)) { block = 256; lds = true; }
+
+    RenderParams p{};
+    for (int a = 0; a < 3; ++a) {
+        p.cam.eye[a] = camera->view_origin[a];
+        p.cam.xo[a] = camera->xaxis_origin[a];
+        p.cam.xd[a] = camera->xaxis_dir[a];
+        p.cam.yd[a] = camera->yaxis_dir[a];
+    }
+    p.cam.vw = camera->viewport_width;
+    p.cam.vh = camera->viewport_height;
+    p.cam.max_w = max_w; p.cam.max_h = max_h;
+    p.cam.spp = camera->samples_per_pixel;
+    p.cam.depth = camera->bounce_depth;
+    p.off = h.off;
+    p.scene_image = ds->image;
+    p.tex = ds->tex;
+    p.texels = ds->texels;
+    p.seed_key = mix64(seed + 0x9E3779B97F4A7C15ull); // seed_key(), host side
+    p.cols = 2 * max_w + 1;
+    p.row_first = row_first; p.row_stride = row_stride; p.n_rows = n_rows;
+    const int half = camera->samples_per_pixel / 2;
+    p.k = half < 5 ? half : 5; // min 5 (spp / 2), Scene.fs:172
+    p.chunk = chunk;
+    p.accum = (int32_t *) d_accum;
+    p.rgb = (uint8_t *) d_rgb;
+    unsigned slot;
+    {
+        std::lock_guard<std::mutex> lock(const_cast<rt_scene *>(scene)->mu);
+        slot = ds->next_slot++ % RT_SCRATCH_SLOTS;
+    }
+    unsigned char *scr = ds->scratch + (size_t) slot * RT_SCRATCH_BYTES;
+    p.counters = (unsigned long long *) scr;
+    p.queue = (unsigned int *) (scr + 64);
+
+    const size_t ldsBytes = (lds ? (size_t) h.off.total : 0u) + (size_t) (block / 64) * RTD_WAVE_WORDS(chunk) * 4u;
+    render_fn fn = pick_kernel(lds, count, block);
+    HIP_TRY(hipFuncSetAttribute((const void *) fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes));
+    int perCu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, (const void *) fn, block, ldsBytes));
+    if (perCu < 1) return fail(RT_ERR_HIP, "render kernel does not fit on a CU (occupancy 0)");
+    if (g_blocks_per_cu > 0 && g_blocks_per_cu < perCu) perCu = g_blocks_per_cu;
+    const uint64_t nLocal = (uint64_t) n_rows * (uint64_t) p.cols;
+    const uint64_t units = (nLocal + (uint64_t) chunk - 1) / (uint64_t) chunk;
+    uint64_t grid = (uint64_t) ds->cu_count * (uint64_t) perCu;
+    const uint64_t wavesPerBlock = (uint64_t) block / 64u;
+    const uint64_t needBlocks = (units + wavesPerBlock - 1) / wavesPerBlock;
+    if (grid > needBlocks) grid = needBlocks;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (stats) {
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+    }
+    HIP_TRY(hipMemsetAsync(scr, 0, RT_SCRATCH_BYTES, st));
+    if (grid > 0) {
+        if (stats) HIP_TRY(hipEventRecord(ev0, st));
+        hipLaunchKernelGGL(fn, dim3((unsigned) grid), dim3((unsigned) block), ldsBytes, st, p);
+        HIP_TRY(hipGetLastError());
+        if (stats) HIP_TRY(hipEventRecord(ev1, st));
+    }
+    if (stats) {
+        HIP_TRY(hipStreamSynchronize(st));
+        unsigned long long c[8] = {0};
+        HIP_TRY(hipMemcpy(c, scr, sizeof(c), hipMemcpyDeviceToHost));
+        float ms = 0.f;
+        if (grid > 0) HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+        (void) hipEventDestroy(ev0);
+        (void) hipEventDestroy(ev1);
+        memset(stats, 0, sizeof(*stats));
+        stats->rays = c[0]; stats->aabb_tests = c[1]; stats->prim_tests = c[2]; stats->reflections = c[3];
+        stats->samples = c[4]; stats->pixels_early = c[5];
+        stats->pixels = nLocal;
+        stats->kernel_ms = ms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RT_OK;
+}
+
+int rt_render(const rt_scene *scene, const rt_camera *camera, int32_t max_w, int32_t max_h, uint64_t seed, int32_t device,
+              int32_t row_first, int32_t row_stride, int32_t n_rows, uint32_t flags, int32_t *accum_host, uint8_t *rgb_host, rt_stats *stats) {
+    int rc = check_geometry(camera, max_w, max_h, row_first, row_stride, n_rows);
+    if (rc != RT_OK) return rc;
+    if (n_rows > 0 && !accum_host) return fail(RT_ERR_INVALID_ARGUMENT, "accum_host is NULL");
+    rc = need_device(device);
+    if (rc != RT_OK) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t npx = (size_t) n_rows * (size_t) (2 * max_w + 1);
+    int32_t *d_accum = nullptr;
+    uint8_t *d_rgb = nullptr;
+    if (npx > 0) {
+        HIP_TRY(hipMalloc((void **) &d_accum, npx * 16u));
+        if (rgb_host) {
+            hipError_t e = hipMalloc((void **) &d_rgb, npx * 3u);
+            if (e != hipSuccess) { (void) hipFree(d_accum); return fail(RT_ERR_HIP, std::string("hipMalloc rgb: ") + hipGetErrorString(e)); }
+        }
+    }
+    rt_stats local;
+    rc = rt_render_device(scene, camera, max_w, max_h, seed, device, row_first, row_stride, n_rows, flags, d_accum, d_rgb, nullptr, &local);
+    if (rc == RT_OK && npx > 0) {
+        hipError_t e = hipMemcpy(accum_host, d_accum, npx * 16u, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && rgb_host) e = hipMemcpy(rgb_host, d_rgb, npx * 3u, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RT_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    }
+    (void) hipFree(d_accum);
+    (void) hipFree(d_rgb);
+    if (rc == RT_OK && stats) {
+        *stats = local;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return rc;
+}
+
+// ---- output side ------------------------------------------------------------------------------------------
+uint8_t rt_gamma_correct(uint8_t b) { return rth::gamma_correct(b); }
+
+int64_t rt_format_ppm(const uint8_t *rgb, int32_t rows, int32_t cols, int32_t gamma_correct, char *out, size_t out_capacity) {
+    if (!rgb || rows <= 0 || cols <= 0) { fail(RT_ERR_INVALID_ARGUMENT, "bad image"); return -RT_ERR_INVALID_ARGUMENT; }
+    std::string s = rth::format_ppm(rgb, rows, cols, gamma_correct != 0);
+    if (out && out_capacity > s.size()) { memcpy(out, s.data(), s.size()); out[s.size()] = 0; }
+    return (int64_t) s.size();
+}
+
+int rt_write_ppm(const char *path, const uint8_t *rgb, int32_t rows, int32_t cols, int32_t gamma_correct) {
+    if (!path || !rgb || rows <= 0 || cols <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad image or path");
+    std::string s = rth::format_ppm(rgb, rows, cols, gamma_correct != 0);
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(RT_ERR_IO, std::string("cannot open ") + path);
+    const size_t w = fwrite(s.data(), 1, s.size(), f);
+    const int c = fclose(f);
+    if (w != s.size() || c != 0) return fail(RT_ERR_IO, std::string("short write to ") + path);
+    return RT_OK;
+}
+
+} // extern "C"
+
+// ============================================================================================================
+// Device unit hooks: tiny kernels that call the SAME inlined device functions the render kernel uses.
+// ============================================================================================================
+namespace {
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void) hipFree(p); }
+    hipError_t alloc(size_t count) { n = count; return count ? hipMalloc((void **) &p, count * sizeof(T)) : hipSuccess; }
+    hipError_t up(const T *h) { return n ? hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice) : hipSuccess; }
+    hipError_t down(T *h) { return n ? hipMemcpy(h, p, n * sizeof(T), hipMemcpyDeviceToHost) : hipSuccess; }
+};
+
+__global__ void k_float_producer(Rng r, int n, double *out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        for (int i = 0; i < n; ++i) out[i] = rng_get(r);
+}
+__global__ void k_stream_state(uint64_t seedKey, int n, const uint64_t *pixel, const uint32_t *sample, uint32_t *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng r = stream_for(seedKey, pixel[i], sample[i]);
+    out[i * 4] = r.x; out[i * 4 + 1] = r.y; out[i * 4 + 2] = r.z; out[i * 4 + 3] = r.w;
+}
+__global__ void k_bbox_hits(int n, const double *rays, const double *boxes, int32_t *hit) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *r = rays + i * 6, *b = boxes + i * 6;
+    d2 bx, by, bz;
+    bx.x = b[0]; bx.y = b[3]; by.x = b[1]; by.y = b[4]; bz.x = b[2]; bz.y = b[5];
+    hit[i] = bbox_hits(1.0 / r[3], 1.0 / r[4], 1.0 / r[5], mk(r[0], r[1], r[2]), bx, by, bz) ? 1 : 0;
+}
+__global__ void k_sphere_isect(int n, const double *rays, const double *sph, double *t) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *r = rays + i * 6, *s = sph + i * 4;
+    t[i] = sphere_first_intersection(mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), mk(s[0], s[1], s[2]), s[3] * s[3]);
+}
+__global__ void k_plane_isect(int n, const double *rays, const double *pl, double *t) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *r = rays + i * 6, *p = pl + i * 6;
+    t[i] = plane_intersection(mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), mk(p[0], p[1], p[2]), mk(p[3], p[4], p[5]));
+}
+RTD_INLINE uint32_t ld_rgb(const uint8_t *p) { return (uint32_t) p[0] | ((uint32_t) p[1] << 8) | ((uint32_t) p[2] << 16); }
+RTD_INLINE void st_rgb(uint8_t *p, uint32_t c) { p[0] = (uint8_t) c; p[1] = (uint8_t) (c >> 8); p[2] = (uint8_t) (c >> 16); }
+__global__ void k_pixel_combine(int n, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st_rgb(out + i * 3, pix_combine(ld_rgb(a + i * 3), ld_rgb(b + i * 3)));
+}
+__global__ void k_pixel_darken(int n, const uint8_t *p, const double *albedo, uint8_t *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st_rgb(out + i * 3, pix_darken(albedo[i], ld_rgb(p + i * 3)));
+}
+__global__ void k_arith(int op, int n, const double *a, const double *b, double *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r;
+    switch (op) {
+    case 0: r = 1.0 / a[i]; break;
+    case 1: r = sqrt(a[i]); break;
+    case 2: r = rint(a[i]); break;
+    case 3: r = a[i] / b[i]; break;
+    default: r = pow5(a[i]); break;
+    }
+    out[i] = r;
+}
+
+struct HookScene { RenderParams p; };
+static SceneView<false> host_view_params(const DeviceScene *ds, const rth::HostScene &h, RenderParams &p) {
+    p = RenderParams{};
+    p.off = h.off;
+    p.scene_image = ds->image;
+    p.tex = ds->tex;
+    p.texels = ds->texels;
+    return SceneView<false>{};
+}
+
+__global__ void k_reflection(const RenderParams p, int n, const int32_t *obj, const double *ray_in, const uint8_t *col_in,
+                             const double *strike, uint32_t *rng, int32_t *absorbed, uint8_t *col_out, double *ray_out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SceneView<false> sc = make_view<false>(p, nullptr);
+    const double *r = ray_in + i * 6, *s = strike + i * 3;
+    V3 o = mk(r[0], r[1], r[2]), d = mk(r[3], r[4], r[5]);
+    uint32_t c = ld_rgb(col_in + i * 3);
+    Rng g; g.x = rng[i * 4]; g.y = rng[i * 4 + 1]; g.z = rng[i * 4 + 2]; g.w = rng[i * 4 + 3];
+    bool ab = reflection<false>(sc, obj[i], mk(s[0], s[1], s[2]), o, d, c, g);
+    absorbed[i] = ab ? 1 : 0;
+    st_rgb(col_out + i * 3, c);
+    double *ro = ray_out + i * 6;
+    ro[0] = o.x; ro[1] = o.y; ro[2] = o.z; ro[3] = d.x; ro[4] = d.y; ro[5] = d.z;
+    rng[i * 4] = g.x; rng[i * 4 + 1] = g.y; rng[i * 4 + 2] = g.z; rng[i * 4 + 3] = g.w;
+}
+__global__ void k_hit_object(const RenderParams p, int n, const double *rays, int32_t *hit, double *strike, uint32_t *counters) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SceneView<false> sc = make_view<false>(p, nullptr);
+    const double *r = rays + i * 6;
+    V3 o = mk(r[0], r[1], r[2]), d = mk(r[3], r[4], r[5]);
+    Counters cnt; cnt.rays = cnt.aabb = cnt.prim = cnt.refl = 0;
+    double t;
+    int obj = hit_object<false, true>(sc, o, d, t, cnt);
+    hit[i] = obj;
+    V3 sp = walk(o, d, t);
+    if (strike) {
+        const double nanv = __builtin_nan("");
+        strike[i * 3] = obj < 0 ? nanv : sp.x; strike[i * 3 + 1] = obj < 0 ? nanv : sp.y; strike[i * 3 + 2] = obj < 0 ? nanv : sp.z;
+    }
+    if (counters) { counters[i * 2] = cnt.aabb; counters[i * 2 + 1] = cnt.prim; }
+}
+__global__ void k_trace_ray(const RenderParams p, int depth, int n, const double *rays, uint32_t *rng, uint8_t *col_out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SceneView<false> sc = make_view<false>(p, nullptr);
+    const double *r = rays + i * 6;
+    Rng g; g.x = rng[i * 4]; g.y = rng[i * 4 + 1]; g.z = rng[i * 4 + 2]; g.w = rng[i * 4 + 3];
+    Counters cnt; cnt.rays = cnt.aabb = cnt.prim = cnt.refl = 0;
+    uint32_t c = trace_ray<false, false>(sc, depth, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), g, cnt);
+    st_rgb(col_out + i * 3, c);
+    rng[i * 4] = g.x; rng[i * 4 + 1] = g.y; rng[i * 4 + 2] = g.z; rng[i * 4 + 3] = g.w;
+}
+__global__ void k_texture(const RenderParams p, int tex, int n, const double *pts, double *uv, uint8_t *col) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double u[2] = {__builtin_nan(""), __builtin_nan("")};
+    uint32_t c = texture_colour_at(p.tex, p.texels, tex, mk(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]), u);
+    if (uv) { uv[i * 2] = u[0]; uv[i * 2 + 1] = u[1]; }
+    st_rgb(col + i * 3, c);
+}
+
+static inline unsigned blocks_for(int n) { return (unsigned) ((n + 255) / 256); }
+
+static int hook_scene_params(int device, const rt_scene *scene, RenderParams &p) {
+    if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
+    int rc = need_device(device);
+    if (rc != RT_OK) return rc;
+    DeviceScene *ds = nullptr;
+    rc = device_scene(const_cast<rt_scene *>(scene), device, &ds);
+    if (rc != RT_OK) return rc;
+    (void) host_view_params(ds, scene->host, p);
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_dev_float_producer(int32_t device, const uint32_t state[4], int32_t n, double *out) {
+    if (!state || !out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    int rc = need_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf<double> d;
+    HIP_TRY(d.alloc((size_t) n));
+    Rng r; r.x = state[0]; r.y = state[1]; r.z = state[2]; r.w = state[3];
+    if (n) hipLaunchKernelGGL(k_float_producer, dim3(1), dim3(64), 0, 0, r, n, d.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(d.down(out));
+    return RT_OK;
+}
+
+int rt_dev_stream_state(int32_t device, uint64_t seed, int32_t n, const uint64_t *pixel, const uint32_t *sample, uint32_t *state_out) {
+    if (!pixel || !sample || !state_out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    int rc = need_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf<uint64_t> dp; DevBuf<uint32_t> dsm, dout;
+    HIP_TRY(dp.alloc((size_t) n)); HIP_TRY(dsm.alloc((size_t) n)); HIP_TRY(dout.alloc((size_t) n * 4));
+    HIP_TRY(dp.up(pixel)); HIP_TRY(dsm.up(sample));
+    if (n) hipLaunchKernelGGL(k_stream_state, dim3(blocks_for(n)), dim3(256), 0, 0, mix64(seed + 0x9E3779B97F4A7C15ull), n, dp.p, dsm.p, dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dout.down(state_out));
+    return RT_OK;
+}
+
+int rt_dev_bbox_hits(int32_t device, int32_t n, const double *rays, const double *boxes, int32_t *hit_out) {
+    if (!rays || !boxes || !hit_out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    int rc = need_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf<double> dr, db; DevBuf<int32_t> dh;
+    HIP_TRY(dr.alloc((size_t) n * 6)); HIP_TRY(db.alloc((size_t) n * 6)); HIP_TRY(dh.alloc((size_t) n));
+    HIP_TRY(dr.up(rays)); HIP_TRY(db.up(boxes));
+    if (n) hipLaunchKernelGGL(k_bbox_hits, dim3(blocks_for(n)), dim3(256), 0, 0, n, dr.p, db.p, dh.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dh.down(hit_out));
+    return RT_OK;
+}
+
+int rt_dev_sphere_first_intersection(int32_t device, int32_t n, const double *rays, const double *spheres, double *t_out) {
+    if (!rays || !spheres || !t_out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    int rc = need_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf<double> dr, dsph, dt;
+    HIP_TRY(dr.alloc((size_t) n * 6)); HIP_TRY(dsph.alloc((size_t) n * 4)); HIP_TRY(dt.alloc((size_t) n));
+    HIP_TRY(dr.up(rays)); HIP_TRY(dsph.up(spheres));
+    if (n) hipLaunchKernelGGL(k_sphere_isect, dim3(blocks_for(n)), dim3(256), 0, 0, n, dr.p, dsph.p, dt.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dt.down(t_out));
+    return RT_OK;
+}
+
+int rt_dev_plane_intersection(int32_t device, int32_t n, const double *rays, const double *planes, double *t_out) {
+    if (!rays || !planes || !t_out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    int rc = need_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf<double> dr, dpl, dt;
+    HIP_TRY(dr.alloc((size_t) n * 6)); HIP_TRY(dpl.alloc((size_t) n * 6)); HIP_TRY(dt.alloc((size_t) n));
+    HIP_TRY(dr.up(rays)); HIP_TRY(dpl.up(planes));
+    if (n) hipLaunchKernelGGL(k_plane_isect, dim3(blocks_for(n)), dim3(256), 0, 0, n, dr.p, dpl.p, dt.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dt.down(t_out));
+    return RT_OK;
+}
+
+int rt_dev_pixel_combine(int32_t device, int32_t n, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+    if (!a || !b || !out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    int rc = need_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf<uint8_t> da, db, dout;
+    HIP_TRY(da.alloc((size_t) n * 3)); HIP_TRY(db.alloc((size_t) n * 3)); HIP_TRY(dout.alloc((size_t) n * 3));
+    HIP_TRY(da.up(a)); HIP_TRY(db.up(b));
+    if (n) hipLaunchKernelGGL(k_pixel_combine, dim3(blocks_for(n)), dim3(256), 0, 0, n, da.p, db.p, dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dout.down(out));
+    return RT_OK;
+}
+
+int rt_dev_pixel_darken(int32_t device, int32_t n, const uint8_t *p, const double *albedo, uint8_t *out) {
+    if (!p || !albedo || !out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    int rc = need_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf<uint8_t> dp, dout; DevBuf<double> da;
+    HIP_TRY(dp.alloc((size_t) n * 3)); HIP_TRY(da.alloc((size_t) n)); HIP_TRY(dout.alloc((size_t) n * 3));
+    HIP_TRY(dp.up(p)); HIP_TRY(da.up(albedo));
+    if (n) hipLaunchKernelGGL(k_pixel_darken, dim3(blocks_for(n)), dim3(256), 0, 0, n, dp.p, da.p, dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dout.down(out));
+    return RT_OK;
+}
+
+int rt_dev_arith(int32_t device, int32_t op, int32_t n, const double *a, const double *b, double *out) {
+    if (!a || !out || n < 0 || op < 0 || op > 4 || (op == 3 && !b)) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    int rc = need_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf<double> da, db, dout;
+    HIP_TRY(da.alloc((size_t) n)); HIP_TRY(db.alloc(b ? (size_t) n : 0)); HIP_TRY(dout.alloc((size_t) n));
+    HIP_TRY(da.up(a));
+    if (b) HIP_TRY(db.up(b));
+    if (n) hipLaunchKernelGGL(k_arith, dim3(blocks_for(n)), dim3(256), 0, 0, op, n, da.p, db.p, dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dout.down(out));
+    return RT_OK;
+}
+
+int rt_dev_reflection(int32_t device, const rt_scene *scene, int32_t n, const int32_t *index, const double *ray_in, const uint8_t *colour_in,
+                      const double *strike, uint32_t *rng_state, int32_t *absorbed, uint8_t *colour_out, double *ray_out) {
+    if (!index || !ray_in || !colour_in || !strike || !rng_state || !absorbed || !colour_out || !ray_out || n < 0)
+        return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    RenderParams p;
+    int rc = hook_scene_params(device, scene, p);
+    if (rc != RT_OK) return rc;
+    std::vector<int32_t> obj((size_t) n);
+    for (int i = 0; i < n; ++i) {
+        if (index[i] < 0 || (size_t) index[i] >= scene->host.origToObj.size()) return fail(RT_ERR_INVALID_ARGUMENT, "hittable index out of range");
+        obj[(size_t) i] = scene->host.origToObj[(size_t) index[i]];
+    }
+    DevBuf<int32_t> dobj, dab; DevBuf<double> dri, dst, dro; DevBuf<uint8_t> dci, dco; DevBuf<uint32_t> drng;
+    HIP_TRY(dobj.alloc((size_t) n)); HIP_TRY(dab.alloc((size_t) n)); HIP_TRY(dri.alloc((size_t) n * 6)); HIP_TRY(dst.alloc((size_t) n * 3));
+    HIP_TRY(dro.alloc((size_t) n * 6)); HIP_TRY(dci.alloc((size_t) n * 3)); HIP_TRY(dco.alloc((size_t) n * 3)); HIP_TRY(drng.alloc((size_t) n * 4));
+    HIP_TRY(dobj.up(obj.data())); HIP_TRY(dri.up(ray_in)); HIP_TRY(dst.up(strike)); HIP_TRY(dci.up(colour_in)); HIP_TRY(drng.up(rng_state));
+    if (n) hipLaunchKernelGGL(k_reflection, dim3(blocks_for(n)), dim3(256), 0, 0, p, n, dobj.p, dri.p, dci.p, dst.p, drng.p, dab.p, dco.p, dro.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dab.down(absorbed)); HIP_TRY(dco.down(colour_out)); HIP_TRY(dro.down(ray_out)); HIP_TRY(drng.down(rng_state));
+    return RT_OK;
+}
+
+int rt_dev_hit_object(int32_t device, const rt_scene *scene, int32_t n, const double *rays, int32_t *hit_index, double *strike, uint32_t *counters) {
+    if (!rays || !hit_index || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    RenderParams p;
+    int rc = hook_scene_params(device, scene, p);
+    if (rc != RT_OK) return rc;
+    DevBuf<double> dr, dsk; DevBuf<int32_t> dh; DevBuf<uint32_t> dc;
+    HIP_TRY(dr.alloc((size_t) n * 6)); HIP_TRY(dh.alloc((size_t) n)); HIP_TRY(dsk.alloc(strike ? (size_t) n * 3 : 0)); HIP_TRY(dc.alloc(counters ? (size_t) n * 2 : 0));
+    HIP_TRY(dr.up(rays));
+    if (n) hipLaunchKernelGGL(k_hit_object, dim3(blocks_for(n)), dim3(256), 0, 0, p, n, dr.p, dh.p, dsk.p, dc.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dh.down(hit_index));
+    for (int i = 0; i < n; ++i) if (hit_index[i] >= 0) hit_index[i] = scene->host.objToOrig[(size_t) hit_index[i]];
+    if (strike) HIP_TRY(dsk.down(strike));
+    if (counters) HIP_TRY(dc.down(counters));
+    return RT_OK;
+}
+
+int rt_dev_trace_ray(int32_t device, const rt_scene *scene, int32_t bounce_depth, int32_t n, const double *rays, uint32_t *rng_state, uint8_t *colour_out) {
+    if (!rays || !rng_state || !colour_out || n < 0 || bounce_depth < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    RenderParams p;
+    int rc = hook_scene_params(device, scene, p);
+    if (rc != RT_OK) return rc;
+    DevBuf<double> dr; DevBuf<uint32_t> drng; DevBuf<uint8_t> dc;
+    HIP_TRY(dr.alloc((size_t) n * 6)); HIP_TRY(drng.alloc((size_t) n * 4)); HIP_TRY(dc.alloc((size_t) n * 3));
+    HIP_TRY(dr.up(rays)); HIP_TRY(drng.up(rng_state));
+    if (n) hipLaunchKernelGGL(k_trace_ray, dim3(blocks_for(n)), dim3(256), 0, 0, p, bounce_depth, n, dr.p, drng.p, dc.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dc.down(colour_out)); HIP_TRY(drng.down(rng_state));
+    return RT_OK;
+}
+
+int rt_dev_texture_colour_at(int32_t device, const rt_scene *scene, int32_t texture, int32_t n, const double *points, double *uv_out, uint8_t *colour_out) {
+    if (!points || !colour_out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!scene || texture < 0 || (size_t) texture >= scene->host.texRecs.size()) return fail(RT_ERR_INVALID_ARGUMENT, "texture index out of range");
+    RenderParams p;
+    int rc = hook_scene_params(device, scene, p);
+    if (rc != RT_OK) return rc;
+    DevBuf<double> dp, duv; DevBuf<uint8_t> dc;
+    HIP_TRY(dp.alloc((size_t) n * 3)); HIP_TRY(duv.alloc(uv_out ? (size_t) n * 2 : 0)); HIP_TRY(dc.alloc((size_t) n * 3));
+    HIP_TRY(dp.up(points));
+    if (n) hipLaunchKernelGGL(k_texture, dim3(blocks_for(n)), dim3(256), 0, 0, p, texture, n, dp.p, duv.p, dc.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (uv_out) HIP_TRY(duv.down(uv_out));
+    HIP_TRY(dc.down(colour_out));
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,15 @@
+"""Import shim: the package directory is `ray-tracing-fsharp_amd/` (a hyphen is not importable by name).
+
+`import ray_tracing_fsharp_amd` loads that directory as a regular package under this module's name.
+"""
+import importlib.util as _ilu
+import os as _os
+import sys as _sys
+
+_dir = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "ray-tracing-fsharp_amd")
+_spec = _ilu.spec_from_file_location(
+    __name__, _os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir]
+)
+_mod = _ilu.module_from_spec(_spec)
+_sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)
