@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config, on N GPUs of one node.
+
+Metric: Mray/s (primary + secondary rays = Scene.hitObject calls per second), whole job.
+Workload at N=1 (and, row-sharded, at N>1): config 3 = the RTIOW final scene (SampleImages.randomSpheres), the reference's
+"1200x800" half-extents = 2401x1601 pixels, 500 spp, 50 bounces, adaptive sampling as in Scene.renderPixel.
+A "step" is one full frame: every rank renders its interleaved rows, then one gather of the accumulators to rank 0.
+
+Launch: `python bench.py --gpus 1 --steps K --warmup W`, or for N>1
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(st) -> int:
+    """56 B per ray-AABB test (6 doubles + 2 links), 32 B per ray-primitive test (centre + r^2),
+    40 B material record per shaded vertex, 4 B packed RGB per finished sample."""
+    return 56 * st["aabb_tests"] + 32 * st["prim_tests"] + 40 * st["reflections"] + 4 * st["samples"]
+
+
+def cpu_baseline(objs, cam, w, h, seed, target_rows):
+    """The oracle (kind "port": a C++ restatement, the F# reference cannot run here) on all host cores, on a bounded
+    sample of the SAME workload: `target_rows` image rows spread evenly over the frame."""
+    import oracle as orc
+
+    rows = 2 * h + 1
+    stride = max(1, rows // target_rows)
+    first = stride // 2
+    n = len(range(first, rows, stride))
+    threads = max(1, orc.hardware_threads())
+    scene = orc.OracleScene(objs)
+    t0 = time.perf_counter()
+    _, _, st = scene.render_rows(w, h, cam.to_abi(), seed=seed, row_first=first, row_stride=stride, n_rows=n, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": round(st["rays"] / dt / 1e6, 4), "unit": "Mray/s", "cores": threads, "kind": "port",
+            "sample": f"{n} of {rows} image rows (every {stride}th from {first}) of the same frame, {st['rays']} rays in {dt:.1f} s; "
+                      f"oracle = C++ restatement of the F# path, the .NET reference cannot run in this image",
+            "rays": st["rays"], "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=500)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--pixels", type=int, default=800, help="the reference's `pixels` (maxHeightCoord); image is (3*pixels+1)x(2*pixels+1)")
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--cpu-rows", type=int, default=16, help="image rows in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import ray_tracing_fsharp_amd as rt
+    from ray_tracing_fsharp_amd import distributed as rtd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available() or rt.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.block or args.chunk:
+        rt.set_launch_config(args.block, args.chunk)
+
+    objs, cam, w, h = rt.sample_images.config3_final(seed=args.seed, spp=args.spp, depth=args.depth, pixels=args.pixels)
+    scene = rt.Scene.make(objs)
+    rows, cols = 2 * h + 1, 2 * w + 1
+    first, stride, n = rtd.shard_rows(rows, rank, world)
+    n_pad = (rows + world - 1) // world
+    local = torch.zeros((n_pad, cols, 4), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        rtd.render_shard_device(scene, cam, w, h, args.seed, local_rank, first, stride, n, local, stream=stream.cuda_stream)
+        return rtd.gather_frame(local, rows, cols, rank, world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # the counters of one launch (deterministic for a seed): an untimed replica with the counting kernel variant
+    st = rtd.render_shard_device(scene, cam, w, h, args.seed, local_rank, first, stride, n, local, stream=stream.cuda_stream,
+                                 counters=True, want_stats=True)
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev0.record(stream)  # HIP events on the stream the kernel is launched on
+        rtd.render_shard_device(scene, cam, w, h, args.seed, local_rank, first, stride, n, local, stream=stream.cuda_stream)
+        ev1.record(stream)
+        frame = rtd.gather_frame(local, rows, cols, rank, world)
+        ev1.synchronize()
+        k_ms += ev0.elapsed_time(ev1)
+    fence()
+    dt = time.perf_counter() - t0
+
+    tot = torch.tensor([dt, float(st["rays"]), float(st["aabb_tests"]), float(st["prim_tests"]), float(st["reflections"]),
+                        float(st["samples"]), float(st["pixels_early"]), k_ms / max(1, args.steps)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt = float(mx[0])
+        job = {k: int(sm[i + 1]) for i, k in enumerate(("rays", "aabb_tests", "prim_tests", "reflections", "samples", "pixels_early"))}
+        kernel_ms = float(mx[7])
+    else:
+        job = {k: int(st[k]) for k in ("rays", "aabb_tests", "prim_tests", "reflections", "samples", "pixels_early")}
+        kernel_ms = float(tot[7])
+
+    if rank == 0:
+        ms_per_step = dt * 1e3 / args.steps
+        value = job["rays"] / (ms_per_step * 1e-3) / 1e6
+        # dominant (only) kernel: rtd::render_kernel.  achieved = this rank's algorithmic bytes per launch / its mean launch time
+        rank_bytes = algorithmic_bytes(st)
+        achieved = rank_bytes / (kernel_ms * 1e-3) / 1e9
+        info = scene.info()
+        out = {
+            "metric": "Mray/s (primary+secondary)", "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"RTIOW final random-spheres scene (SampleImages.randomSpheres recipe, seed {args.seed}), "
+                                   f"maxW={w} maxH={h} -> {cols}x{rows} px, {args.spp} spp adaptive, {args.depth} bounces",
+                       "spheres_bounded": info["n_bounded"], "unbounded": info["n_unbounded"], "tree_nodes": info["n_nodes"],
+                       "lds_resident_scene": bool(info["lds_resident"]), "sharding": f"rows interleaved over {world} rank(s), one gather"},
+            "job": {**job, "pixels": rows * cols, "wall_s_per_frame": round(ms_per_step / 1e3, 4),
+                    "ray_sphere_tests_per_s": round(job["prim_tests"] / (ms_per_step * 1e-3), 1),
+                    "aabb_tests_per_s": round(job["aabb_tests"] / (ms_per_step * 1e-3), 1),
+                    "samples_per_s": round(job["samples"] / (ms_per_step * 1e-3), 1),
+                    "early_exit_fraction": round(job["pixels_early"] / (rows * cols), 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "kernel": "rtd::render_kernel", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": rank_bytes,
+                         "note": "algorithmic scene bytes (served from LDS); physical HBM traffic is in profiles/ and DESIGN.md"},
+        }
+        if world == 1 and args.cpu_rows > 0:
+            out["cpu_baseline"] = cpu_baseline(objs, cam, w, h, args.seed, args.cpu_rows)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

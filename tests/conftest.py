@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def rt():
+    import ray_tracing_fsharp_amd as m
+    return m
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import oracle as m  # test infrastructure: the CPU restatement the HIP path is checked against
+    return m

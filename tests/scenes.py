@@ -1,0 +1,60 @@
+"""Small seeded scenes shared by the parity tests: every material, planes, textures, negative radii."""
+import dataclasses
+
+import numpy as np
+
+import ray_tracing_fsharp_amd as rt
+from ray_tracing_fsharp_amd import sample_images as si
+
+P, V = rt.Point.make, rt.Vector.make
+S, PS, H = rt.SphereStyle, rt.InfinitePlaneStyle, rt.Hittable
+Tex = rt.Texture.Colour
+Px = rt.Pixel
+
+
+def unit(x, y, z):
+    return rt.Vector.unitise(V(x, y, z))
+
+
+def checker_image(h=16, w=32, seed=5):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+
+
+def all_materials(spp=24, depth=12, pixels=20):
+    """Every SphereStyle and InfinitePlaneStyle, bounded + unbounded, a hollow (negative radius) unbounded shell,
+    a checkered UV-ramp texture, an image texture on a light; 16:9 like the reference's small scenes."""
+    aspect = 16.0 / 9.0
+    cam = dataclasses.replace(rt.Camera.makeBasic(spp, 1.0, aspect, P(0.0, 0.3, -1.0), unit(0.0, -0.05, 1.0), V(0.0, 1.0, 0.0)), BounceDepth=depth)
+    chk = rt.ParameterisedTexture.Checkered(rt.ParameterisedTexture.UvRamp("u", 0, "v"), rt.ParameterisedTexture.UvRamp(100, "u", "v"), 50.0)
+    img = rt.ParameterisedTexture.Image(checker_image())
+    objs = [
+        H.Sphere(rt.Sphere.make(S.LambertReflection(0.9, Tex(Px(25, 50, 120))), P(0.0, 0.0, 1.0), 0.5)),
+        H.Sphere(rt.Sphere.make(S.PureReflection(0.95, rt.ParameterisedTexture.toTexture((0.5, P(1.1, 0.0, 1.0)), chk)), P(1.1, 0.0, 1.0), 0.5)),
+        H.Sphere(rt.Sphere.make(S.Glass(0.95, Tex(rt.Colour.White), 1.5), P(-1.1, 0.0, 1.0), 0.5)),
+        H.UnboundedSphere(rt.Sphere.make(S.Glass(1.0, Tex(rt.Colour.White), 1.0 / 1.5), P(-1.1, 0.0, 1.0), -0.4)),
+        H.Sphere(rt.Sphere.make(S.FuzzedReflection(0.8, Tex(Px(255, 100, 0)), 0.3), P(0.5, 0.9, 1.6), 0.35)),
+        H.Sphere(rt.Sphere.make(S.Dielectric(0.9, Tex(Px(200, 255, 200)), 1.4, 0.7), P(-0.5, 0.9, 1.6), 0.35)),
+        H.Sphere(rt.Sphere.make(S.LightSourceCap(Px(255, 240, 200)), P(0.0, 1.9, 1.2), 0.4)),
+        H.Sphere(rt.Sphere.make(S.LightSource(rt.ParameterisedTexture.toTexture((0.3, P(1.6, 1.2, 2.0)), img)), P(1.6, 1.2, 2.0), 0.3)),
+        H.Sphere(rt.Sphere.make(S.Glass(1.0, Tex(rt.Colour.White), 1.5), P(0.2, -0.1, 0.2), -0.15)),  # bounded negative radius: never hit
+        H.InfinitePlane(rt.InfinitePlane.make(PS.FuzzedReflection(0.85, Px(255, 200, 200), 0.4), P(0.0, -0.5, 0.0), unit(0.0, 1.0, 0.0))),
+        H.InfinitePlane(rt.InfinitePlane.make(PS.PureReflection(0.8, rt.Colour.White), P(0.0, 0.0, 4.0), unit(0.3, 0.0, -1.0))),
+        H.InfinitePlane(rt.InfinitePlane.make(PS.LambertReflection(0.7, Px(120, 220, 120)), P(-3.0, 0.0, 0.0), unit(1.0, 0.0, 0.0))),
+        H.InfinitePlane(rt.InfinitePlane.make(PS.LightSource(Tex(Px(90, 90, 160))), P(0.0, 0.0, -5.0), unit(0.0, 0.0, 1.0))),
+        H.UnboundedSphere(rt.Sphere.make(S.LightSource(Tex(Px(200, 200, 200))), P(0.0, 0.0, 0.0), 200.0)),
+    ]
+    return objs, cam, int(aspect * float(pixels)), pixels
+
+
+def small_final(seed=7, spp=40, depth=50, pixels=16):
+    """The RTIOW final scene (config 3) at thumbnail size: same geometry and tree, few pixels."""
+    return si.config3_final(seed=seed, spp=spp, depth=depth, pixels=pixels)
+
+
+def random_rays(n, seed, origin_scale=3.0):
+    rng = np.random.default_rng(seed)
+    o = rng.normal(size=(n, 3)) * origin_scale
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([o, d], axis=1)

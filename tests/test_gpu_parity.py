@@ -1,0 +1,282 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
+Bar: bit-exact (integer sums, bytes, indices, and every double the unit hooks return)."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_f64(a, b):
+    """Bit-for-bit equality of doubles, NaN (= ValueNone) positions included."""
+    a, b = np.ascontiguousarray(a, np.float64), np.ascontiguousarray(b, np.float64)
+    na, nb = np.isnan(a), np.isnan(b)
+    return a.shape == b.shape and np.array_equal(na, nb) and np.array_equal(a[~na].view(np.uint64), b[~nb].view(np.uint64))
+
+
+def test_device_present(rt):
+    assert rt.device_count() >= 1
+
+
+# ---- arithmetic the contract relies on -------------------------------------------------------------------------
+@pytest.mark.parametrize("op", [0, 1, 2, 3])
+def test_ieee_division_sqrt_rint_bit_exact(rt, orc, op):
+    rng = np.random.default_rng(100 + op)
+    a = np.concatenate([rng.normal(size=200000) * 10.0 ** rng.integers(-30, 30, size=200000), [0.0, -0.0, 1.0, 0.5, 1.5, 2.5, 254.5, 1e-310, np.inf]])
+    b = np.concatenate([rng.normal(size=200000) * 10.0 ** rng.integers(-30, 30, size=200000), [1.0, 3.0, 7.0, 255.0, 1e300, 1e-300, 0.1, 3.0, 2.0]])
+    if op == 1:
+        a = np.abs(a)
+    assert _same_f64(rt.hooks.arith(op, a, b), orc.arith(op, a, b))
+
+
+def test_pow5_matches_libm(rt, orc):
+    """Math.Pow(x, 5.0) (Sphere.fs:290): the device's double-double x^5 against glibc pow on the range Glass uses."""
+    rng = np.random.default_rng(9)
+    x = np.concatenate([rng.random(1000000) * 2.0, rng.random(100000) * 1e-3, [0.0, 1.0, 2.0, 0.5, 1e-200, 1.0 - 2 ** -53]])
+    assert _same_f64(rt.hooks.arith(4, x), orc.arith(4, x))
+
+
+# ---- unit hooks --------------------------------------------------------------------------------------------------
+def test_float_producer_and_stream_state(rt, orc):
+    assert _same_f64(rt.hooks.float_producer((1, 2, 3, 4), 1000), orc.float_producer((1, 2, 3, 4), 1000))
+    rng = np.random.default_rng(3)
+    px = rng.integers(0, 2 ** 40, size=5000, dtype=np.uint64)
+    sm = rng.integers(0, 5000, size=5000, dtype=np.uint32)
+    for seed in (0, 1, 2 ** 63 + 12345):
+        assert np.array_equal(rt.hooks.stream_state(seed, px, sm), orc.stream_state(seed, px, sm))
+
+
+def test_pixel_ops_exhaustive(rt, orc):
+    a = np.repeat(np.arange(256, dtype=np.uint8), 256)
+    b = np.tile(np.arange(256, dtype=np.uint8), 256)
+    A3, B3 = np.stack([a, b, a], 1), np.stack([b, a, b], 1)
+    assert np.array_equal(rt.hooks.pixel_combine(A3, B3), orc.pixel_combine(A3, B3))
+    alb = np.linspace(0.0, 1.0, len(a))
+    assert np.array_equal(rt.hooks.pixel_darken(A3, alb), orc.pixel_darken(A3, alb))
+    half = np.full(len(a), 0.5)
+    assert np.array_equal(rt.hooks.pixel_darken(A3, half), orc.pixel_darken(A3, half))  # x.5 ties: half-to-even
+
+
+def test_bbox_hits_incl_axis_aligned_rays(rt, orc):
+    rays = scenes.random_rays(100000, 11)
+    rng = np.random.default_rng(12)
+    lo = rng.normal(size=(100000, 3)) * 2
+    boxes = np.concatenate([lo, lo + np.abs(rng.normal(size=(100000, 3)))], axis=1)
+    # axis-aligned directions give +-inf inverse directions and NaN products (BoundingBox.fs:25-28)
+    rays[:3000, 3:] = np.eye(3)[rng.integers(0, 3, 3000)] * rng.choice([-1.0, 1.0], size=(3000, 1))
+    rays[:1000, :3] = boxes[:1000, :3]  # origins exactly on a box corner
+    boxes[50000:51000, :3], boxes[50000:51000, 3:] = boxes[50000:51000, 3:].copy(), boxes[50000:51000, :3].copy()  # inverted boxes
+    assert np.array_equal(rt.hooks.bbox_hits(rays, boxes), orc.bbox_hits(rays, boxes))
+
+
+def test_sphere_and_plane_intersection(rt, orc):
+    rays = scenes.random_rays(200000, 21)
+    rng = np.random.default_rng(22)
+    sph = np.concatenate([rng.normal(size=(200000, 3)) * 3, rng.normal(size=(200000, 1)) * 2], axis=1)
+    sph[:2000, 3] = np.linalg.norm(sph[:2000, :3] - rays[:2000, :3], axis=1)  # origin on the surface: roots near 0 and the 1e-8 band
+    assert _same_f64(rt.hooks.sphere_first_intersection(rays, sph), orc.sphere_first_intersection(rays, sph))
+    n = rng.normal(size=(200000, 3))
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    pl = np.concatenate([rng.normal(size=(200000, 3)) * 3, n], axis=1)
+    assert _same_f64(rt.hooks.plane_intersection(rays, pl), orc.plane_intersection(rays, pl))
+
+
+def _scene_pair(rt, orc, objs):
+    return rt.Scene.make(objs), orc.OracleScene(objs)
+
+
+def test_hit_object_indices_strikes_and_counters(rt, orc):
+    for objs, *_ in (scenes.all_materials(), scenes.small_final()):
+        s, o = _scene_pair(rt, orc, objs)
+        rays = scenes.random_rays(60000, 31, origin_scale=4.0)
+        rays[:20000, :3] = [13.0, 2.0, -3.0]
+        h1, s1, c1 = rt.hooks.hit_object(s, rays)
+        h2, s2, c2 = o.hit_object(rays)
+        assert np.array_equal(h1, h2)
+        assert _same_f64(s1, s2)
+        assert np.array_equal(c1, c2)  # BoundingBox.hits / Hittable.hits call counts per ray
+
+
+def test_reflection_every_style(rt, orc):
+    objs, *_ = scenes.all_materials()
+    s, o = _scene_pair(rt, orc, objs)
+    rng = np.random.default_rng(41)
+    n_per = 4000
+    for idx, h in enumerate(objs):
+        rays = scenes.random_rays(n_per, 50 + idx, origin_scale=2.0)
+        if h.sphere is not None:
+            c, r = np.array(h.sphere.Centre), abs(h.sphere.Radius)
+            d = rng.normal(size=(n_per, 3))
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            strike = c + r * d
+            rays[: n_per // 2, :3] = c + 0.3 * r * rng.normal(size=(n_per // 2, 3)) / 2  # half the rays start inside
+            rays[-50:, 3:] = -d[-50:]  # along the normal: degenerate plane (Sphere.fs:72-75, 121-124)
+            rays[-50:, :3] = strike[-50:] + d[-50:]
+        else:
+            p0, nn = np.array(h.plane.Point), np.array(h.plane.Normal)
+            t = rng.normal(size=(n_per, 3))
+            strike = p0 + t - np.outer(t @ nn, nn)
+            rays[-50:, 3:] = -nn
+        col = rng.integers(0, 256, size=(n_per, 3), dtype=np.uint8)
+        st = rng.integers(1, 2 ** 31 - 1, size=(n_per, 4), dtype=np.uint32)
+        a1, c1, r1, g1 = rt.hooks.reflection(s, np.full(n_per, idx), rays, col, strike, st)
+        a2, c2, r2, g2 = o.reflection(np.full(n_per, idx), rays, col, strike, st)
+        assert np.array_equal(a1, a2), f"absorbed differs for hittable {idx}"
+        assert np.array_equal(c1, c2), f"colour differs for hittable {idx}"
+        assert _same_f64(r1, r2), f"outgoing ray differs for hittable {idx}"
+        assert np.array_equal(g1, g2), f"rng state differs for hittable {idx}"
+
+
+def test_texture_lookup(rt, orc):
+    objs, *_ = scenes.all_materials()
+    s, o = _scene_pair(rt, orc, objs)
+    rng = np.random.default_rng(61)
+    for tex, centre, radius in ((2, (1.1, 0.0, 1.0), 0.5), (3, (1.6, 1.2, 2.0), 0.3)):
+        d = rng.normal(size=(20000, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        pts = np.array(centre) + radius * d
+        uv1, c1 = rt.hooks.texture_colour_at(s, tex, pts)
+        uv2, c2 = o.texture_colour_at(tex, pts)
+        # acos/atan2/sin are libm on the oracle side and OCML on the device: <= 2 ulp on (u, v) ...
+        assert np.max(np.abs(uv1 - uv2)) < 1e-14
+        # ... which moves a truncating texel/ramp index only within an ulp of an integer boundary
+        assert np.mean(np.any(c1 != c2, axis=1)) < 1e-3
+
+
+def test_trace_ray_paths(rt, orc):
+    for (objs, cam, w, h), depth in ((scenes.all_materials(), 12), (scenes.small_final(), 50), (scenes.small_final(), 0)):
+        s, o = _scene_pair(rt, orc, objs)
+        rays = scenes.random_rays(30000, 71, origin_scale=0.5)
+        rays[:, :3] += [0.0, 0.5, -1.0]
+        st = np.random.default_rng(72).integers(1, 2 ** 31 - 1, size=(30000, 4), dtype=np.uint32)
+        c1, g1 = rt.hooks.trace_ray(s, depth, rays, st)
+        c2, g2 = o.trace_ray(depth, rays, st)
+        assert np.array_equal(c1, c2)
+        assert np.array_equal(g1, g2)
+
+
+# ---- whole renders ------------------------------------------------------------------------------------------------
+def _render_both(rt, orc, objs, cam, w, h, seed, **shard):
+    s, o = _scene_pair(rt, orc, objs)
+    res = s.render_rows(w, h, cam, seed=seed, counters=True, **shard)
+    acc, rgb, st = o.render_rows(w, h, cam.to_abi(), seed=seed, threads=8, **shard)
+    return res, acc, rgb, st
+
+
+def _assert_render_equal(res, acc, rgb, st):
+    assert np.array_equal(res.accum, acc), f"{np.count_nonzero(np.any(res.accum != acc, axis=-1))} pixels differ"
+    assert np.array_equal(res.rgb, rgb)
+    for k in ("rays", "aabb_tests", "prim_tests", "reflections", "samples", "pixels", "pixels_early"):
+        assert res.stats[k] == st[k], k
+
+
+def test_config1_empty_scene_is_black_with_one_sample(rt, orc):
+    objs, cam, w, h = rt.sample_images.config1_empty()
+    res, acc, rgb, st = _render_both(rt, orc, objs, cam, w, h, seed=1)
+    _assert_render_equal(res, acc, rgb, st)
+    assert res.accum.shape == (101, 201, 4)
+    assert np.all(res.accum[..., 0] == 1) and np.all(res.accum[..., 1:] == 0)
+
+
+@pytest.mark.parametrize("seed", [0, 12345])
+def test_all_materials_render(rt, orc, seed):
+    objs, cam, w, h = scenes.all_materials()
+    _assert_render_equal(*_render_both(rt, orc, objs, cam, w, h, seed=seed))
+
+
+@pytest.mark.parametrize("spp", [1, 2, 3, 9, 10, 11, 12, 40])
+def test_adaptive_sampling_counts(rt, orc, spp):
+    """Scene.renderPixel (Scene.fs:172-194): firstTrial = min 5 (spp/2); spp=2 takes 3 samples; counts are 2k+1 or spp."""
+    objs, cam, w, h = scenes.all_materials(spp=spp, pixels=8)
+    res, acc, rgb, st = _render_both(rt, orc, objs, cam, w, h, seed=5)
+    _assert_render_equal(res, acc, rgb, st)
+    k = min(5, spp // 2)
+    assert set(np.unique(res.accum[..., 0])) <= {2 * k + 1, max(2 * k + 1, spp)}
+
+
+def test_config2_three_lambert_reduced(rt, orc):
+    objs, cam, w, h = rt.sample_images.config2_three_lambert(spp=30, pixels=27)
+    _assert_render_equal(*_render_both(rt, orc, objs, cam, w, h, seed=2))
+
+
+def test_config3_final_scene_rows(rt, orc):
+    """BASELINE config 3 at FULL geometry (2401x1601, 500 spp, depth 50): three image rows through sky, horizon, spheres."""
+    objs, cam, w, h = rt.sample_images.config3_final()
+    for row in (100, 640, 1000):
+        _assert_render_equal(*_render_both(rt, orc, objs, cam, w, h, seed=2024, row_first=row, row_stride=1, n_rows=1))
+
+
+def test_hot_pink_when_bounce_limit_is_hit(rt, orc):
+    """Scene.fs:98,114: a path still alive after depth+1 hits returns HotPink; two facing mirrors make every path do so."""
+    P, H, PS = rt.Point.make, rt.Hittable, rt.InfinitePlaneStyle
+    up = rt.Vector.unitise(rt.Vector.make(0.0, 0.0, 1.0))
+    objs = [H.InfinitePlane(rt.InfinitePlane.make(PS.PureReflection(1.0, rt.Colour.White), P(0.0, 0.0, 5.0), up)),
+            H.InfinitePlane(rt.InfinitePlane.make(PS.PureReflection(1.0, rt.Colour.White), P(0.0, 0.0, -5.0), up))]
+    cam = dataclasses.replace(rt.Camera.makeBasic(3, 1.0, 1.0, P(0.0, 0.0, 0.0), up, rt.Vector.make(0.0, 1.0, 0.0)), BounceDepth=7)
+    res, acc, rgb, st = _render_both(rt, orc, objs, cam, 4, 4, seed=3)
+    _assert_render_equal(res, acc, rgb, st)
+    assert np.all(res.rgb == np.array(rt.Colour.HotPink, np.uint8))
+    assert res.stats["rays"] == res.stats["samples"] * 8
+
+
+@pytest.mark.parametrize("name", ["spheres", "shiny-floor", "fuzzy-floor", "total-refraction", "glass", "moved-camera", "textured-sphere"])
+def test_reference_catalogue_thumbnails(rt, orc, name):
+    """The reference's own SampleImages scenes (SampleImages.fs:59-810) at thumbnail size, 20 spp."""
+    objs, cam, w, h = rt.sample_images.get(name)()
+    cam = dataclasses.replace(cam, SamplesPerPixel=20)
+    w, h = max(1, w // 20), max(1, h // 20)
+    res, acc, rgb, st = _render_both(rt, orc, objs, cam, w, h, seed=8)
+    if name == "textured-sphere":  # libm vs OCML ulp differences can flip a texel: allow a handful of pixels
+        assert np.count_nonzero(np.any(res.accum != acc, axis=-1)) <= 2
+    else:
+        _assert_render_equal(res, acc, rgb, st)
+
+
+def test_sharding_does_not_change_pixels(rt):
+    """Streams are keyed by the GLOBAL pixel index: interleaved shards reassemble to the single-call frame."""
+    objs, cam, w, h = scenes.all_materials(pixels=14)
+    s = rt.Scene.make(objs)
+    full = s.render_rows(w, h, cam, seed=77)
+    for world in (2, 3, 8):
+        out = np.zeros_like(full.accum)
+        for rank in range(world):
+            part = s.render_rows(w, h, cam, seed=77, row_first=rank, row_stride=world)
+            out[rank::world] = part.accum
+        assert np.array_equal(out, full.accum)
+
+
+def test_launch_configs_agree(rt):
+    objs, cam, w, h = scenes.small_final(spp=24, pixels=10)
+    s = rt.Scene.make(objs)
+    base = s.render_rows(w, h, cam, seed=4).accum
+    try:
+        for block, chunk in ((256, 8), (512, 64), (1024, 16), (1024, 1)):
+            rt.set_launch_config(block, chunk)
+            assert np.array_equal(s.render_rows(w, h, cam, seed=4).accum, base), (block, chunk)
+    finally:
+        rt.set_launch_config(0, 0)
+
+
+def test_seed_changes_the_image_and_same_seed_repeats(rt):
+    objs, cam, w, h = scenes.all_materials(pixels=10)
+    s = rt.Scene.make(objs)
+    a, b, c = (s.render_rows(w, h, cam, seed=x).accum for x in (1, 1, 2))
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+def test_monte_carlo_energy_property_full_size(rt):
+    """Size-independent property at BASELINE config 2's full size (801x451, 100 spp, depth 50): every Count is 11 or
+    100, sums are bounded by 255*Count, sky pixels (dome seen directly) are exactly the dome colour and stop early."""
+    objs, cam, w, h = rt.sample_images.config2_three_lambert()
+    s = rt.Scene.make(objs)
+    res = s.render_rows(w, h, cam, seed=6, counters=True)
+    cnt = res.accum[..., 0]
+    assert set(np.unique(cnt)) <= {11, 100}
+    assert np.all(res.accum[..., 1:] <= 255 * cnt[..., None]) and np.all(res.accum[..., 1:] >= 0)
+    top = res.accum[0]
+    assert np.all(top[:, 0] == 11) and np.all(top[:, 1:] == 200 * 11)
+    assert res.stats["samples"] == int(cnt.sum()) and res.stats["pixels_early"] == int((cnt == 11).sum())
+    assert res.stats["rays"] >= res.stats["samples"]
