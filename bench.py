@@ -28,23 +28,33 @@ def algorithmic_bytes(st) -> int:
     return 56 * st["aabb_tests"] + 32 * st["prim_tests"] + 40 * st["reflections"] + 4 * st["samples"]
 
 
-def cpu_baseline(objs, cam, w, h, seed, target_rows):
-    """The oracle (kind "port": a C++ restatement, the F# reference cannot run here) on all host cores, on a bounded
-    sample of the SAME workload: `target_rows` image rows spread evenly over the frame."""
+def cpu_baseline(objs, cam, w, h, seed, target_seconds):
+    """The oracle (kind "port": a C++ restatement; the F#/.NET reference cannot run in this image) on all host cores, on a
+    bounded sample of the SAME workload: every `stride`-th image row of the frame, sized by a short calibration pass so the
+    timed pass is about `target_seconds` of CPU wall time."""
     import oracle as orc
 
     rows = 2 * h + 1
-    stride = max(1, rows // target_rows)
-    first = stride // 2
-    n = len(range(first, rows, stride))
     threads = max(1, orc.hardware_threads())
     scene = orc.OracleScene(objs)
-    t0 = time.perf_counter()
-    _, _, st = scene.render_rows(w, h, cam.to_abi(), seed=seed, row_first=first, row_stride=stride, n_rows=n, threads=threads)
-    dt = time.perf_counter() - t0
+
+    def run(stride):
+        first = stride // 2
+        n = len(range(first, rows, stride))
+        t0 = time.perf_counter()
+        _, _, st = scene.render_rows(w, h, cam.to_abi(), seed=seed, row_first=first, row_stride=stride, n_rows=n, threads=threads)
+        return st, time.perf_counter() - t0, first, n
+
+    cal_stride = max(1, rows // 32)
+    st, dt, first, n = run(cal_stride)  # calibration: ~32 rows spread over the frame
+    rate = st["rays"] / dt
+    full_rays = st["rays"] * cal_stride
+    stride = max(1, min(cal_stride, int(round(full_rays / max(rate * target_seconds, 1.0)))))
+    if stride < cal_stride:
+        st, dt, first, n = run(stride)
     return {"value": round(st["rays"] / dt / 1e6, 4), "unit": "Mray/s", "cores": threads, "kind": "port",
-            "sample": f"{n} of {rows} image rows (every {stride}th from {first}) of the same frame, {st['rays']} rays in {dt:.1f} s; "
-                      f"oracle = C++ restatement of the F# path, the .NET reference cannot run in this image",
+            "sample": f"{n} of {rows} image rows (every {stride}th from row {first}) of the same frame: {st['rays']} rays in {dt:.1f} s; "
+                      f"oracle = C++ restatement of the F# path (the .NET reference cannot run in this image)",
             "rays": st["rays"], "seconds": round(dt, 2)}
 
 
@@ -57,7 +67,7 @@ def main():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--pixels", type=int, default=800, help="the reference's `pixels` (maxHeightCoord); image is (3*pixels+1)x(2*pixels+1)")
     ap.add_argument("--seed", type=int, default=2024)
-    ap.add_argument("--cpu-rows", type=int, default=16, help="image rows in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample (0 = skip)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     args = ap.parse_args()
@@ -158,8 +168,8 @@ def main():
                          "kernel": "rtd::render_kernel", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": rank_bytes,
                          "note": "algorithmic scene bytes (served from LDS); physical HBM traffic is in profiles/ and DESIGN.md"},
         }
-        if world == 1 and args.cpu_rows > 0:
-            out["cpu_baseline"] = cpu_baseline(objs, cam, w, h, args.seed, args.cpu_rows)
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(objs, cam, w, h, args.seed, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -19,7 +19,8 @@
 // Every function cites the reference file:line it restates (paths relative to /root/reference/RayTracing).
 //
 // Build: g++ -O2 -std=c++17 -ffp-contract=off -fno-fast-math (RyuJIT never fuses mul+add; F7/F8 in SURVEY.md).
-// libm: Math.Pow/Acos/Atan2/Sin on Linux .NET call the C runtime, i.e. glibc -- the same functions used here.
+// libm: Math.Acos/Atan2/Sin on Linux .NET call the C runtime, i.e. glibc -- the same functions used here (textures only).
+// Math.Pow(x, 5.0) is taken as the correctly rounded power (see SphereM::pow5).
 
 #include "../include/rtfs_amd.h"
 
@@ -503,6 +504,15 @@ static void refract(bool inside, const Ray &normal, Point strikePoint, double in
     RayM::overwriteWithMake(strikePoint, outgoingLine, incomingLight.ray);
 }
 
+// Math.Pow (x, 5.0) (Sphere.fs:290).  Math.Pow is the platform's C runtime pow: glibc on Linux, whose result is within
+// 1 ulp but NOT always correctly rounded (measured: 0.08 % of x in [0,2] are 1 ulp off), the UCRT on Windows, etc.
+// The oracle takes the platform-independent value those approximate: x^5 rounded once, computed here in binary128
+// (5 multiplies, error < 2^-110) -- deliberately a different route from the HIP path's double-double product.
+static inline double pow5(double x) {
+    __float128 q = (__float128) x;
+    return (double) (q * q * q * q * q);
+}
+
 // Sphere.reflection (Sphere.fs:150-300).  Returns true with `absorbed` set for ValueSome colour.
 static bool reflection(const TextureTable &tt, const SphereStyle &style, Point centre, double radius, double radiusSquared,
                        bool flipped, LightRay &incomingLight, Point strikePoint, FloatProducer &rand, Pixel &absorbed) {
@@ -586,7 +596,7 @@ static bool reflection(const TextureTable &tt, const SphereStyle &style, Point c
             double sphereRefractance = inside ? 1.0 / style.ior : style.ior;
             double param = (1.0 - sphereRefractance) / (1.0 + sphereRefractance);
             param = param * param;
-            reflectionProb = param + (1.0 - param) * (std::pow((1.0 - incomingCos), 5.0)); // `**` = Math.Pow
+            reflectionProb = param + (1.0 - param) * (pow5((1.0 - incomingCos))); // `** 5.0` = Math.Pow, see pow5 above
         }
         if (r < reflectionProb) {
             reflectWithoutFuzz(normal, strikePoint, incomingLight);
@@ -1149,23 +1159,31 @@ int orc_render(const orc_scene *sc, const rt_camera *cam, int32_t max_w, int32_t
     if (row_first < 0 || (n_rows > 0 && row_first + (n_rows - 1) * row_stride >= rowsIter)) { g_err = "rows out of range"; return RT_ERR_INVALID_ARGUMENT; }
     if (n_threads <= 0) n_threads = 1;
     auto t0 = std::chrono::steady_clock::now();
-    std::atomic<int> next{0};
+    // Work units are blocks of 64 consecutive pixels of the shard (not whole rows), so that every host core has work
+    // even when the shard has few rows; (pixel, sample) streams make the result independent of the schedule.
+    const int64_t nPixels = (int64_t) n_rows * (int64_t) colsIter;
+    const int64_t unitPixels = 64;
+    const int64_t nUnits = (nPixels + unitPixels - 1) / unitPixels;
+    std::atomic<int64_t> next{0};
     std::vector<Counters> cnts((size_t) n_threads);
     std::vector<uint64_t> earlies((size_t) n_threads, 0);
     auto worker = [&](int tid) {
         Counters &cnt = cnts[(size_t) tid];
         for (;;) {
-            int i = next.fetch_add(1);
-            if (i >= n_rows) break;
-            int r = row_first + i * row_stride;
-            int row = max_h - r - 1; // Scene.fs:219
-            for (int c = 0; c < colsIter; ++c) {
-                int col = c - max_w; // Scene.fs:226
+            int64_t u = next.fetch_add(1);
+            if (u >= nUnits) break;
+            int64_t lpEnd = std::min(nPixels, (u + 1) * unitPixels);
+            for (int64_t lp = u * unitPixels; lp < lpEnd; ++lp) {
+                int i = (int) (lp / colsIter);
+                int c = (int) (lp - (int64_t) i * colsIter);
+                int r = row_first + i * row_stride;
+                int row = max_h - r - 1; // Scene.fs:219
+                int col = c - max_w;     // Scene.fs:226
                 PixelStats st;
                 bool early = false;
                 uint64_t pixelIndex = (uint64_t) r * (uint64_t) colsIter + (uint64_t) c;
                 Pixel p = SceneM::renderPixel(s, seed, pixelIndex, camera, max_w, max_h, row, col, st, early, cnt);
-                size_t o = (size_t) i * (size_t) colsIter + (size_t) c;
+                size_t o = (size_t) lp;
                 if (accum) { accum[o * 4 + 0] = st.Count; accum[o * 4 + 1] = st.SumRed; accum[o * 4 + 2] = st.SumGreen; accum[o * 4 + 3] = st.SumBlue; }
                 if (rgb) { rgb[o * 3 + 0] = p.Red; rgb[o * 3 + 1] = p.Green; rgb[o * 3 + 2] = p.Blue; }
                 if (early) earlies[(size_t) tid]++;
@@ -1317,7 +1335,8 @@ int orc_arith(int32_t op, int32_t n, const double *a, const double *b, double *o
         case 1: out[i] = std::sqrt(a[i]); break;
         case 2: out[i] = std::rint(a[i]); break;
         case 3: out[i] = a[i] / b[i]; break;
-        case 4: out[i] = std::pow(a[i], 5.0); break;
+        case 4: out[i] = SphereM::pow5(a[i]); break;
+        case 5: out[i] = std::pow(a[i], 5.0); break; // the C runtime's pow, for comparison
         default: g_err = "bad op"; return RT_ERR_INVALID_ARGUMENT;
         }
     }

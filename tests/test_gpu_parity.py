@@ -32,11 +32,16 @@ def test_ieee_division_sqrt_rint_bit_exact(rt, orc, op):
     assert _same_f64(rt.hooks.arith(op, a, b), orc.arith(op, a, b))
 
 
-def test_pow5_matches_libm(rt, orc):
-    """Math.Pow(x, 5.0) (Sphere.fs:290): the device's double-double x^5 against glibc pow on the range Glass uses."""
+def test_pow5_is_the_correctly_rounded_power(rt, orc):
+    """Math.Pow(x, 5.0) (Sphere.fs:290): the device's double-double x^5 equals the oracle's binary128 x^5 bit for bit on
+    the range Glass uses ((1 - cos) in [0, 2]); the C runtime's pow (what .NET calls) is within 1 ulp of both and equal
+    on > 99.8 % of inputs (measured 99.92 %: glibc's pow is not always correctly rounded)."""
     rng = np.random.default_rng(9)
-    x = np.concatenate([rng.random(1000000) * 2.0, rng.random(100000) * 1e-3, [0.0, 1.0, 2.0, 0.5, 1e-200, 1.0 - 2 ** -53]])
-    assert _same_f64(rt.hooks.arith(4, x), orc.arith(4, x))
+    x = np.concatenate([rng.random(1000000) * 2.0, rng.random(100000) * 1e-3, [0.0, 1.0, 2.0, 0.5, 1e-200, 1.0 - 2 ** -53, -1e-17]])
+    dev, ref, crt = rt.hooks.arith(4, x), orc.arith(4, x), orc.arith(5, x)
+    assert _same_f64(dev, ref)
+    assert np.mean(dev == crt) > 0.998
+    assert np.all(np.abs(dev - crt) <= np.spacing(np.abs(crt)))
 
 
 # ---- unit hooks --------------------------------------------------------------------------------------------------
