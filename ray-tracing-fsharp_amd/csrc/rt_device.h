@@ -131,13 +131,16 @@ RTD_INLINE double pow5(double x) {
 }
 
 // ---- flattened scene ------------------------------------------------------------------------------------
-// Image layout (bytes; every section 16-byte aligned; built by rt_host.hpp, staged verbatim into LDS):
-//   box  [n_nodes][3] d2   {min,max} per axis                     48 B/node  (3 x ds_read_b128, 48-B stride)
-//   link [n_nodes]    i2   {skip, prim}                             8 B/node  (ds_read_b64)
-//   geo  [n_obj][3]   d2   sphere {cx,cy}{cz,r^2}{radius,0} | plane {px,py}{pz,nx}{ny,nz}   48 B/object
-//   meta [n_obj]      i2   {kind|style<<2|flipped<<5, rgb|(texture+1)<<24}                   8 B/object
-//   mat  [n_obj][3]   double {albedo, fuzz|ior, prob}                                       24 B/object
+// Image layout (bytes; every section 16-byte aligned; built by rt_scene.h, staged verbatim into LDS):
+//   node [n_nodes]   56 B  {lo_x, hi_x, lo_y, hi_y, lo_z, hi_z : double; skip_off, prim : int32}
+//                          skip_off = BYTE offset of the node to visit when this box is missed (n_nodes*56 = end);
+//                          prim = object index of a Leaf, -1 for a Branch.  7 x ds_read_b64 per visit; a 56-B stride
+//                          spreads consecutive records over all 32 eight-byte LDS slots (7 is odd).
+//   geo  [n_obj][3]  d2    sphere {cx,cy}{cz,r^2}{radius,0} | plane {px,py}{pz,nx}{ny,nz}   48 B/object
+//   meta [n_obj]     i2    {kind|style<<2|flipped<<5, rgb|(texture+1)<<24}                   8 B/object
+//   mat  [n_obj][3]  double {albedo, fuzz|ior, prob}                                       24 B/object
 // Objects: bounded spheres first (tree leaves point at them), then the unbounded list in Scene.make order.
+#define RTD_NODE_BYTES 56
 struct TexRec { // global memory only
     uint32_t kind;
     uint32_t rgb;       // packed colour
@@ -151,19 +154,20 @@ struct TexRec { // global memory only
 
 template <bool LDS> struct Ptrs;
 template <> struct Ptrs<true> {
+    typedef const RTD_AS3 unsigned char *bp;
     typedef const RTD_AS3 d2 *d2p;
     typedef const RTD_AS3 i2 *i2p;
     typedef const RTD_AS3 double *dp;
 };
 template <> struct Ptrs<false> {
+    typedef const unsigned char *bp;
     typedef const d2 *d2p;
     typedef const i2 *i2p;
     typedef const double *dp;
 };
 
 template <bool LDS> struct SceneView {
-    typename Ptrs<LDS>::d2p box;
-    typename Ptrs<LDS>::i2p link;
+    typename Ptrs<LDS>::bp node;
     typename Ptrs<LDS>::d2p geo;
     typename Ptrs<LDS>::i2p meta;
     typename Ptrs<LDS>::dp mat;
@@ -173,7 +177,7 @@ template <bool LDS> struct SceneView {
 };
 
 struct SceneOffsets { // byte offsets into the image
-    uint32_t box, link, geo, meta, mat, total;
+    uint32_t node, geo, meta, mat, total;
     int32_t n_nodes, n_bounded, n_unbounded;
 };
 
@@ -183,26 +187,29 @@ struct SceneOffsets { // byte offsets into the image
 struct Counters { uint32_t rays, aabb, prim, refl; };
 
 // ---- BoundingBox.hits (BoundingBox.fs:30-94) ------------------------------------------------------------------
-// Branch-free restatement: the two early bail-outs only skip work, so evaluating all three slabs and AND-ing
-// "not bailed after x", "not bailed after y", "final test after z" gives the same bool.  Note the asymmetry the
-// reference has and this keeps: bail-outs use `0.0 >= tMax`, the final test uses `tMax >= 0.0`.
+// Restated without branches, swaps or select chains; each step below is an identity on the reference's result:
+//  * `if inv < 0 then swap t0 t1` (BoundingBox.fs:52-55): the caller passes near = (inv < 0 ? hi : lo) and
+//    far = (inv < 0 ? lo : hi), so (near - o)*inv IS the swapped t0 and (far - o)*inv the swapped t1, same arithmetic.
+//  * `tMin <- if t0 > tMin then t0 else tMin` == fmax(t0, tMin): tMin starts at -inf and is only ever replaced by a
+//    t0 that compared greater, so it is never NaN; when t0 is NaN both forms keep tMin; on equal values they differ at
+//    most in the sign of a zero, which no later comparison can see.  Likewise tMax and fmin.
+//  * With tMin/tMax never NaN, `not (tMax < tMin || 0.0 >= tMax)` is `tMax >= tMin && tMax > 0.0`; tMin only rises and
+//    tMax only falls over the three axes, so the x- and y-stage tests are implied by the later ones except `tMax_y > 0`
+//    (the reference's asymmetry: bail-outs use `0.0 >= tMax`, the final test `tMax >= 0.0`).
+RTD_INLINE bool bbox_hits_nf(double ix, double iy, double iz, V3 o, double nx, double fx, double ny, double fy, double nz, double fz) {
+    double tMin = __builtin_fmax((nx - o.x) * ix, -__builtin_inf());
+    double tMax = __builtin_fmin((fx - o.x) * ix, __builtin_inf());
+    tMin = __builtin_fmax((ny - o.y) * iy, tMin);
+    tMax = __builtin_fmin((fy - o.y) * iy, tMax);
+    const bool yPos = tMax > 0.0;
+    tMin = __builtin_fmax((nz - o.z) * iz, tMin);
+    tMax = __builtin_fmin((fz - o.z) * iz, tMax);
+    return (tMax >= tMin) & yPos & (tMax >= 0.0);
+}
+// (min,max)-ordered operands, as the unit hook and the reference's tests hand them over
 RTD_INLINE bool bbox_hits(double ix, double iy, double iz, V3 o, d2 bx, d2 by, d2 bz) {
-    double tMin = -__builtin_inf(), tMax = __builtin_inf();
-    double t0 = (bx.x - o.x) * ix, t1 = (bx.y - o.x) * ix;
-    if (ix < 0.0) { double tmp = t1; t1 = t0; t0 = tmp; }
-    tMin = (t0 > tMin) ? t0 : tMin;
-    tMax = (t1 < tMax) ? t1 : tMax;
-    bool ok = !(tMax < tMin || 0.0 >= tMax);
-    t0 = (by.x - o.y) * iy; t1 = (by.y - o.y) * iy;
-    if (iy < 0.0) { double tmp = t1; t1 = t0; t0 = tmp; }
-    tMin = (t0 > tMin) ? t0 : tMin;
-    tMax = (t1 < tMax) ? t1 : tMax;
-    ok = ok && !(tMax < tMin || 0.0 >= tMax);
-    t0 = (bz.x - o.z) * iz; t1 = (bz.y - o.z) * iz;
-    if (iz < 0.0) { double tmp = t1; t1 = t0; t0 = tmp; }
-    tMin = (t0 > tMin) ? t0 : tMin;
-    tMax = (t1 < tMax) ? t1 : tMax;
-    return ok && (tMax >= tMin && tMax >= 0.0);
+    return bbox_hits_nf(ix, iy, iz, o, ix < 0.0 ? bx.y : bx.x, ix < 0.0 ? bx.x : bx.y, iy < 0.0 ? by.y : by.x, iy < 0.0 ? by.x : by.y,
+                        iz < 0.0 ? bz.y : bz.x, iz < 0.0 ? bz.x : bz.y);
 }
 
 // ---- Sphere.firstIntersection (Sphere.fs:349-386); returns NaN for ValueNone ----------------------------------------
@@ -235,32 +242,47 @@ RTD_INLINE double plane_intersection(V3 o, V3 d, V3 p0, V3 n) {
 }
 
 // ---- Scene.hitObject (Scene.fs:62-91) + Scene.bestCandidate (Scene.fs:30-60) ------------------------------------------
-// The recursive left-then-right walk becomes a stackless loop over the pre-order image: a hit box advances to the
-// next node (its left child, or -- for a leaf -- whatever follows it), a missed box jumps to its skip link.
+// The recursive left-then-right walk becomes a stackless loop over the pre-order image: a hit box advances to the next
+// record (its left child, or -- for a leaf -- whatever follows it), a missed box jumps to its skip offset.
+// Leaf primitives are tested OUTSIDE the node loop ("while-while"): a lane that finds a hit leaf box parks until every
+// lane of the wave has one (or has finished), then all run Sphere.firstIntersection together.  The order in which a
+// ray sees its leaves is unchanged, so strict-`<` tie-breaking (Scene.fs:45-47) is unchanged.
 // Returns the object index or -1; `bestLen` is the ray parameter of the hit.
 template <bool LDS, bool COUNT>
 RTD_INLINE int hit_object(const SceneView<LDS> &sc, V3 o, V3 d, double &bestLen, Counters &cnt) {
+    typedef typename Ptrs<LDS>::bp bp;
+    typedef typename Ptrs<LDS>::dp dp;
+    typedef typename Ptrs<LDS>::i2p i2p;
     if (COUNT) cnt.rays++;
-    double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z; // BoundingBox.inverseDirections (BoundingBox.fs:25-28)
+    const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z; // BoundingBox.inverseDirections (BoundingBox.fs:25-28)
+    // byte offsets of the near/far plane of each axis inside a node record (the swap of BoundingBox.fs:52-55)
+    const int nX = ix < 0.0 ? 8 : 0, nY = iy < 0.0 ? 24 : 16, nZ = iz < 0.0 ? 40 : 32;
+    const int fX = nX ^ 8, fY = nY ^ 8, fZ = nZ ^ 8;
     double bestF = __builtin_inf();
     int best = -1;
     bestLen = __builtin_nan("");
-    int n = 0;
-    const int nn = sc.n_nodes;
-    while (n < nn) {
-        d2 bx = sc.box[n * 3 + 0], by = sc.box[n * 3 + 1], bz = sc.box[n * 3 + 2];
-        i2 lk = sc.link[n];
-        if (COUNT) cnt.aabb++;
-        if (bbox_hits(ix, iy, iz, o, bx, by, bz)) {
-            if (lk.y >= 0) { // Leaf: Hittable.hits (Hittable.fs:27-31) -> Sphere.firstIntersection
-                d2 g0 = sc.geo[lk.y * 3 + 0], g1 = sc.geo[lk.y * 3 + 1];
-                if (COUNT) cnt.prim++;
-                double t = sphere_first_intersection(o, d, mk(g0.x, g0.y, g1.x), g1.y);
-                double a = t * t;
-                if (a < bestF) { bestF = a; best = lk.y; bestLen = t; } // strict `<` on t^2 (Scene.fs:45-47); NaN fails
-            }
-            n = n + 1;
-        } else n = lk.x;
+    int off = 0;
+    const int end = sc.n_nodes * RTD_NODE_BYTES;
+    for (;;) {
+        int pending = -1;
+        while (off < end) {
+            bp rec = sc.node + off;
+            const double vnx = *(dp) (rec + nX), vfx = *(dp) (rec + fX);
+            const double vny = *(dp) (rec + nY), vfy = *(dp) (rec + fY);
+            const double vnz = *(dp) (rec + nZ), vfz = *(dp) (rec + fZ);
+            const i2 lk = *(i2p) (rec + 48);
+            if (COUNT) cnt.aabb++;
+            const bool hit = bbox_hits_nf(ix, iy, iz, o, vnx, vfx, vny, vfy, vnz, vfz);
+            off = hit ? off + RTD_NODE_BYTES : lk.x;
+            if (hit && lk.y >= 0) { pending = lk.y; break; }
+        }
+        if (pending < 0) break;
+        // Leaf: Hittable.hits (Hittable.fs:27-31) -> Sphere.firstIntersection
+        const d2 g0 = sc.geo[pending * 3 + 0], g1 = sc.geo[pending * 3 + 1];
+        if (COUNT) cnt.prim++;
+        const double t = sphere_first_intersection(o, d, mk(g0.x, g0.y, g1.x), g1.y);
+        const double a = t * t;
+        if (a < bestF) { bestF = a; best = pending; bestLen = t; } // strict `<` on t^2 (Scene.fs:45-47); NaN fails
     }
     // UnboundedObjects, in array order, accepted only when Float.compare a bestFloat = Less (Scene.fs:77-86)
     for (int u = 0; u < sc.n_unbounded; ++u) {

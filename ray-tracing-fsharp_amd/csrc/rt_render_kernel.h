@@ -60,8 +60,7 @@ template <bool LDS> RTD_INLINE SceneView<LDS> make_view(const RenderParams &p, c
 template <> RTD_INLINE SceneView<true> make_view<true>(const RenderParams &p, const unsigned char *lds_base) {
     SceneView<true> v;
     const RTD_AS3 unsigned char *b = (const RTD_AS3 unsigned char *) lds_base;
-    v.box = (Ptrs<true>::d2p) (b + p.off.box);
-    v.link = (Ptrs<true>::i2p) (b + p.off.link);
+    v.node = (Ptrs<true>::bp) (b + p.off.node);
     v.geo = (Ptrs<true>::d2p) (b + p.off.geo);
     v.meta = (Ptrs<true>::i2p) (b + p.off.meta);
     v.mat = (Ptrs<true>::dp) (b + p.off.mat);
@@ -72,8 +71,7 @@ template <> RTD_INLINE SceneView<true> make_view<true>(const RenderParams &p, co
 template <> RTD_INLINE SceneView<false> make_view<false>(const RenderParams &p, const unsigned char *) {
     SceneView<false> v;
     const unsigned char *b = p.scene_image;
-    v.box = (const d2 *) (b + p.off.box);
-    v.link = (const i2 *) (b + p.off.link);
+    v.node = b + p.off.node;
     v.geo = (const d2 *) (b + p.off.geo);
     v.meta = (const i2 *) (b + p.off.meta);
     v.mat = (const double *) (b + p.off.mat);

@@ -193,8 +193,7 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
     // ---- device image ----
     rtd::SceneOffsets &off = s.off;
     size_t cur = 0;
-    off.box = (uint32_t) cur;  cur = align16(cur + nn * 48u);
-    off.link = (uint32_t) cur; cur = align16(cur + nn * 8u);
+    off.node = (uint32_t) cur; cur = align16(cur + nn * RTD_NODE_BYTES);
     off.geo = (uint32_t) cur;  cur = align16(cur + nobj * 48u);
     off.meta = (uint32_t) cur; cur = align16(cur + nobj * 8u);
     off.mat = (uint32_t) cur;  cur = align16(cur + nobj * 24u);
@@ -202,15 +201,16 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
     off.n_nodes = (int32_t) nn; off.n_bounded = (int32_t) nb; off.n_unbounded = (int32_t) nu;
     s.image.assign(cur == 0 ? 16 : cur, 0);
     if (cur == 0) off.total = 16;
-    double *pbox = (double *) (s.image.data() + off.box);
-    int32_t *plink = (int32_t *) (s.image.data() + off.link);
+    unsigned char *pnode = s.image.data() + off.node;
     double *pgeo = (double *) (s.image.data() + off.geo);
     int32_t *pmeta = (int32_t *) (s.image.data() + off.meta);
     double *pmat = (double *) (s.image.data() + off.mat);
     for (size_t i = 0; i < nn; ++i) {
-        for (int a = 0; a < 3; ++a) { pbox[i * 6 + (size_t) a * 2] = s.tree.box[i].mn[a]; pbox[i * 6 + (size_t) a * 2 + 1] = s.tree.box[i].mx[a]; }
-        plink[i * 2] = s.tree.skip[i];
-        plink[i * 2 + 1] = s.tree.prim[i];
+        double *bx = (double *) (pnode + i * RTD_NODE_BYTES);
+        int32_t *lk = (int32_t *) (pnode + i * RTD_NODE_BYTES + 48);
+        for (int a = 0; a < 3; ++a) { bx[a * 2] = s.tree.box[i].mn[a]; bx[a * 2 + 1] = s.tree.box[i].mx[a]; }
+        lk[0] = s.tree.skip[i] * RTD_NODE_BYTES; // byte offset of the record to visit on a miss
+        lk[1] = s.tree.prim[i];
     }
     for (size_t j = 0; j < nobj; ++j) {
         const rt_hittable &o = h[(size_t) s.objToOrig[j]];

@@ -1,0 +1,29 @@
+"""One launch of the render kernel on the bench workload (config 3), for rocprofv3 --pmc passes.
+usage: python scripts/one_frame.py [--block B] [--chunk C] [--pixels P] [--spp S] [--launches L]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import ray_tracing_fsharp_amd as rt  # noqa: E402
+from ray_tracing_fsharp_amd import distributed as rtd  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--block", type=int, default=0)
+ap.add_argument("--chunk", type=int, default=0)
+ap.add_argument("--pixels", type=int, default=800)
+ap.add_argument("--spp", type=int, default=500)
+ap.add_argument("--depth", type=int, default=50)
+ap.add_argument("--launches", type=int, default=1)
+ap.add_argument("--counters", action="store_true")
+a = ap.parse_args()
+rt.set_launch_config(a.block, a.chunk)
+objs, cam, w, h = rt.sample_images.config3_final(spp=a.spp, depth=a.depth, pixels=a.pixels)
+scene = rt.Scene.make(objs)
+rows, cols = 2 * h + 1, 2 * w + 1
+local = torch.zeros((rows, cols, 4), dtype=torch.int32, device="cuda:0")
+for _ in range(a.launches):
+    st = rtd.render_shard_device(scene, cam, w, h, 2024, 0, 0, 1, rows, local, counters=a.counters, want_stats=True)
+    print({k: st[k] for k in ("kernel_ms", "rays", "aabb_tests", "prim_tests", "samples")}, flush=True)
