@@ -180,7 +180,7 @@ int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
     out->n_nodes = h.off.n_nodes;
     out->tree_depth = h.tree.depth;
     out->n_textures = (int32_t) h.texRecs.size();
-    out->lds_resident = lds_fits(h, g_block_threads ? g_block_threads : 512, g_chunk_pixels ? g_chunk_pixels : 32) ? 1 : 0;
+    out->lds_resident = lds_fits(h, g_block_threads ? g_block_threads : 1024, g_chunk_pixels ? g_chunk_pixels : 16) ? 1 : 0;
     out->scene_bytes = (int64_t) h.off.total;
     out->texel_bytes = (int64_t) h.texelBlob.size();
     return RT_OK;
@@ -227,8 +227,8 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     const rth::HostScene &h = scene->host;
     hipStream_t st = (hipStream_t) stream;
 
-    int block = g_block_threads ? g_block_threads : 512;
-    int chunk = g_chunk_pixels ? g_chunk_pixels : 32;
+    int block = g_block_threads ? g_block_threads : 1024;
+    int chunk = g_chunk_pixels ? g_chunk_pixels : 16;
     const bool count = (flags & RT_RENDER_COUNTERS) != 0;
     bool lds = lds_fits(h, block, chunk);
     if (!lds && block > 256 && lds_fits(h, 256, chunk)) { block = 256; lds = true; }

@@ -58,3 +58,16 @@ def random_rays(n, seed, origin_scale=3.0):
     d = rng.normal(size=(n, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     return np.concatenate([o, d], axis=1)
+
+
+def earth_thumb(earthmap_rows_top_first, spp=30, pixels=18):
+    """SampleImages.earth (SampleImages.fs:962-1010) at thumbnail size, with the committed decoded texels."""
+    objs, cam, w, h = si.earth(earthmap_rows_top_first)
+    cam = dataclasses.replace(cam, SamplesPerPixel=spp)
+    aspect = 16.0 / 9.0
+    return objs, cam, int(aspect * float(pixels)), pixels
+
+
+def golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))

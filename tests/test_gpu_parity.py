@@ -285,3 +285,64 @@ def test_monte_carlo_energy_property_full_size(rt):
     assert np.all(top[:, 0] == 11) and np.all(top[:, 1:] == 200 * 11)
     assert res.stats["samples"] == int(cnt.sum()) and res.stats["pixels_early"] == int((cnt == 11).sum())
     assert res.stats["rays"] >= res.stats["samples"]
+
+
+# ---- committed golden fixtures and the device-buffer path -----------------------------------------------------------
+@pytest.mark.parametrize("name", ["oracle_all_materials_seed0", "oracle_final_thumb_seed7", "oracle_config2_small_seed2", "oracle_earth_thumb_seed3"])
+def test_hip_reproduces_the_committed_fixtures(rt, name):
+    from test_oracle_render import FIXTURES, KEYS
+
+    g = scenes.golden(name)
+    objs, cam, w, h = FIXTURES[name](rt)
+    res = rt.Scene.make(objs).render_rows(w, h, cam, seed=int(g["seed"]), counters=True)
+    if "earth" in name:  # image-texture lookups go through acos/atan2 (OCML vs libm): a texel may flip on an ulp
+        assert np.count_nonzero(np.any(res.accum != g["accum"], axis=-1)) <= 2
+    else:
+        assert np.array_equal(res.accum, g["accum"]) and np.array_equal(res.rgb, g["rgb"])
+        assert [res.stats[k] for k in KEYS] == g["stats"].tolist()
+
+
+def test_config5_mixed_scene_thumbnail(rt, orc):
+    """BASELINE config 5 geometry (final scene + earth-textured sphere + Dielectric sphere + mirror InfinitePlane), thumbnail."""
+    earth = scenes.golden("earthmap_rgb")["rgb"]
+    objs, cam, w, h = rt.sample_images.config5_mixed(earth, spp=30, pixels=14)
+    res, acc, rgb, st = _render_both(rt, orc, objs, cam, w, h, seed=13)
+    assert np.count_nonzero(np.any(res.accum != acc, axis=-1)) <= 2
+    assert res.stats["samples"] == st["samples"] or abs(res.stats["samples"] - st["samples"]) <= 2 * 30
+
+
+def test_device_buffer_path_and_frame_assembly(rt):
+    """rt_render_device into a torch CUDA tensor on torch's current stream + gather_frame (world = 1), as bench.py uses it."""
+    import torch
+
+    from ray_tracing_fsharp_amd import distributed as rtd
+
+    objs, cam, w, h = scenes.small_final(spp=24, pixels=10)
+    s = rt.Scene.make(objs)
+    want = s.render_rows(w, h, cam, seed=5).accum
+    frame = rtd.render_frame(s, cam, w, h, seed=5, rank=0, world=1, device=0)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), want)
+    # an interleaved shard rendered into a padded buffer, as rank 1 of 3 would
+    first, stride, n = rtd.shard_rows(2 * h + 1, 1, 3)
+    local = torch.zeros(((2 * h + 1 + 2) // 3, 2 * w + 1, 4), dtype=torch.int32, device="cuda:0")
+    st = rtd.render_shard_device(s, cam, w, h, 5, 0, first, stride, n, local, stream=torch.cuda.current_stream().cuda_stream, want_stats=True)
+    assert np.array_equal(local[:n].cpu().numpy(), want[1::3]) and st["pixels"] == n * (2 * w + 1)
+
+
+def test_full_size_config3_properties(rt):
+    """BASELINE config 3 at full size (2401x1601, 500 spp, 50 bounces), through size-independent properties: Count is 11 or
+    500 everywhere, sums bounded by 255*Count, samples = sum of Counts, sky rows are the dome colour exactly, the counters
+    are those of the committed run (deterministic in the seed), and two launches give identical frames."""
+    objs, cam, w, h = rt.sample_images.config3_final()
+    s = rt.Scene.make(objs)
+    a = s.render_rows(w, h, cam, seed=2024, counters=True)
+    b = s.render_rows(w, h, cam, seed=2024)
+    assert np.array_equal(a.accum, b.accum)
+    cnt = a.accum[..., 0].astype(np.int64)
+    assert set(np.unique(cnt)) <= {11, 500}
+    assert np.all(a.accum[..., 1:] >= 0) and np.all(a.accum[..., 1:] <= 255 * cnt[..., None])
+    assert a.stats["samples"] == int(cnt.sum()) and a.stats["pixels_early"] == int((cnt == 11).sum())
+    assert np.all(a.accum[0, :, 0] == 11) and np.all(a.accum[0, :, 1:] == np.array([200, 200, 255]) * 11)
+    assert a.stats["rays"] == a.stats["reflections"]  # the scene is closed: every ray hits something
+    assert (a.stats["rays"], a.stats["aabb_tests"], a.stats["prim_tests"], a.stats["samples"]) == (3502894591, 98205888087, 11481719500, 1079544454)
