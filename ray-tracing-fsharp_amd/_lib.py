@@ -19,12 +19,31 @@ class RtError(RuntimeError):
         self.message = message
 
 
+def _preload_hip_runtime():
+    """A process must hold ONE HIP/HSA runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7,
+    RPATH $ORIGIN); if librtfs_amd.so pulled in /opt/rocm's copy first, a later `import torch` would start a second runtime
+    that finds no GPU.  So when a torch wheel is present, its runtime is loaded first (torch itself is NOT imported) and
+    librtfs_amd.so's NEEDED libamdhip64.so.7 binds to it; without torch the system runtime is used."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C ray-tracing-fsharp_amd/csrc` (hipcc, gfx950). There is no CPU fallback."
         )
+    _preload_hip_runtime()
     return C.CDLL(LIB_PATH)
 
 
