@@ -28,6 +28,21 @@ def algorithmic_bytes(st) -> int:
     return 56 * st["aabb_tests"] + 32 * st["prim_tests"] + 40 * st["reflections"] + 4 * st["samples"]
 
 
+def profiled_traffic():
+    """HBM bytes per launch of the render kernel from the newest committed PMC summary under profiles/ (separate
+    rocprofv3 --pmc passes, scripts/pmc.sh): WRITE_SIZE + 2*FETCH_SIZE KiB (gfx950 reports half the fetched bytes,
+    MI355X_MICROARCH.md "HBM").  None when no summary is committed."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_bench_config_summary.csv")))
+    if not files:
+        return None, None
+    vals = dict(line.strip().split(",") for line in open(files[-1]) if "," in line)
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None, None
+    return int((2.0 * float(vals["FETCH_SIZE"]) + float(vals["WRITE_SIZE"])) * 1024), os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(objs, cam, w, h, seed, target_seconds):
     """The oracle (kind "port": a C++ restatement; the F#/.NET reference cannot run in this image) on all host cores, on a
     bounded sample of the SAME workload: every `stride`-th image row of the frame, sized by a short calibration pass so the
@@ -150,6 +165,7 @@ def main():
         rank_bytes = algorithmic_bytes(st)
         achieved = rank_bytes / (kernel_ms * 1e-3) / 1e9
         info = scene.info()
+        traffic, traffic_src = profiled_traffic() if world == 1 else (None, None)
         out = {
             "metric": "Mray/s (primary+secondary)", "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
@@ -164,7 +180,7 @@ def main():
                     "samples_per_s": round(job["samples"] / (ms_per_step * 1e-3), 1),
                     "early_exit_fraction": round(job["pixels_early"] / (rows * cols), 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "rtd::render_kernel", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": rank_bytes,
                          "note": "algorithmic scene bytes (served from LDS); physical HBM traffic is in profiles/ and DESIGN.md"},
         }
