@@ -201,9 +201,12 @@ const char *rt_last_error(void);   /* thread-local message of the last failing c
 int rt_abi_version(void);
 /* sizeof of the ABI structs as compiled: 0 rt_hittable, 1 rt_texture, 2 rt_camera, 3 rt_scene_info, 4 rt_stats (bindings check their mirrors). */
 size_t rt_abi_sizeof(int which);
-/* Tunables of the render kernel: threads per workgroup (512 or 1024) and pixels per wave work unit (<= 64).
+/* Tunables of the render kernel: threads per workgroup (256, 512, 768 or 1024) and pixels per wave work unit (<= 64).
  * 0 keeps the default.  Process-wide; meant for bench sweeps. */
 int rt_set_launch_config(int32_t block_threads, int32_t chunk_pixels, int32_t blocks_per_cu);
+/* Lane-scheduling thresholds of the render kernel (DESIGN.md "Kernel"): a stage yields once `yield_lanes` lanes wait for
+ * another stage; idle lanes are refilled once `refill_lanes` are idle.  0 keeps the default.  Results never depend on them. */
+int rt_set_schedule(int32_t yield_lanes, int32_t refill_lanes);
 
 /*
  * ---- Device unit hooks ---------------------------------------------------------------------------

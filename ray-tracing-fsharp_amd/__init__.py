@@ -18,3 +18,8 @@ def device_count() -> int:
 def set_launch_config(block_threads: int = 0, chunk_pixels: int = 0, blocks_per_cu: int = 0) -> None:
     from ._lib import check
     check(lib.rt_set_launch_config(block_threads, chunk_pixels, blocks_per_cu))
+
+
+def set_schedule(yield_lanes: int = 0, refill_lanes: int = 0) -> None:
+    from ._lib import check
+    check(lib.rt_set_schedule(yield_lanes, refill_lanes))

@@ -244,47 +244,56 @@ RTD_INLINE double plane_intersection(V3 o, V3 d, V3 p0, V3 n) {
 // ---- Scene.hitObject (Scene.fs:62-91) + Scene.bestCandidate (Scene.fs:30-60) ------------------------------------------
 // The recursive left-then-right walk becomes a stackless loop over the pre-order image: a hit box advances to the next
 // record (its left child, or -- for a leaf -- whatever follows it), a missed box jumps to its skip offset.
-// Leaf primitives are tested OUTSIDE the node loop ("while-while"): a lane that finds a hit leaf box parks until every
-// lane of the wave has one (or has finished), then all run Sphere.firstIntersection together.  The order in which a
-// ray sees its leaves is unchanged, so strict-`<` tie-breaking (Scene.fs:45-47) is unchanged.
-// Returns the object index or -1; `bestLen` is the ray parameter of the hit.
-template <bool LDS, bool COUNT>
-RTD_INLINE int hit_object(const SceneView<LDS> &sc, V3 o, V3 d, double &bestLen, Counters &cnt) {
+// The walk is split into resumable pieces so that the render kernel can interleave the walks of its 64 lanes with the
+// other stages of their paths (rt_render_kernel.h): `Walk` is the state a lane keeps while parked, `WalkCtx` is derived
+// from the ray each time a lane (re)enters the node loop.  The order in which a ray sees its leaves never changes, so the
+// strict-`<` tie-breaking of Scene.fs:45-47 is unchanged.
+struct Walk {
+    int off;        // byte offset of the next node record; >= n_nodes*56 when the tree is exhausted
+    int best;       // bestObject (object index) or -1
+    double bestLen; // bestLength; NaN until something is hit (Scene.fs:64)
+};
+struct WalkCtx {
+    double ix, iy, iz; // BoundingBox.inverseDirections (BoundingBox.fs:25-28)
+    int nX, nY, nZ;    // byte offset of each axis' NEAR plane inside a node record: the swap of BoundingBox.fs:52-55
+    double bestF;      // bestFloat = bestLength^2, +inf until something is hit (Scene.fs:65)
+};
+RTD_INLINE void walk_begin(Walk &w) { w.off = 0; w.best = -1; w.bestLen = __builtin_nan(""); }
+RTD_INLINE WalkCtx walk_ctx(V3 d, const Walk &w) {
+    WalkCtx c;
+    c.ix = 1.0 / d.x; c.iy = 1.0 / d.y; c.iz = 1.0 / d.z;
+    c.nX = c.ix < 0.0 ? 8 : 0; c.nY = c.iy < 0.0 ? 24 : 16; c.nZ = c.iz < 0.0 ? 40 : 32;
+    c.bestF = (w.best < 0) ? __builtin_inf() : w.bestLen * w.bestLen; // `a = point * point` (Scene.fs:45), recomputed
+    return c;
+}
+// One BoundingBox.hits + advance.  Returns the leaf's object index when a Leaf box was hit (its primitive test is then
+// pending), else -1.
+template <bool LDS>
+RTD_INLINE int node_step(const SceneView<LDS> &sc, V3 o, const WalkCtx &c, int &off) {
     typedef typename Ptrs<LDS>::bp bp;
     typedef typename Ptrs<LDS>::dp dp;
     typedef typename Ptrs<LDS>::i2p i2p;
-    if (COUNT) cnt.rays++;
-    const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z; // BoundingBox.inverseDirections (BoundingBox.fs:25-28)
-    // byte offsets of the near/far plane of each axis inside a node record (the swap of BoundingBox.fs:52-55)
-    const int nX = ix < 0.0 ? 8 : 0, nY = iy < 0.0 ? 24 : 16, nZ = iz < 0.0 ? 40 : 32;
-    const int fX = nX ^ 8, fY = nY ^ 8, fZ = nZ ^ 8;
-    double bestF = __builtin_inf();
-    int best = -1;
-    bestLen = __builtin_nan("");
-    int off = 0;
-    const int end = sc.n_nodes * RTD_NODE_BYTES;
-    for (;;) {
-        int pending = -1;
-        while (off < end) {
-            bp rec = sc.node + off;
-            const double vnx = *(dp) (rec + nX), vfx = *(dp) (rec + fX);
-            const double vny = *(dp) (rec + nY), vfy = *(dp) (rec + fY);
-            const double vnz = *(dp) (rec + nZ), vfz = *(dp) (rec + fZ);
-            const i2 lk = *(i2p) (rec + 48);
-            if (COUNT) cnt.aabb++;
-            const bool hit = bbox_hits_nf(ix, iy, iz, o, vnx, vfx, vny, vfy, vnz, vfz);
-            off = hit ? off + RTD_NODE_BYTES : lk.x;
-            if (hit && lk.y >= 0) { pending = lk.y; break; }
-        }
-        if (pending < 0) break;
-        // Leaf: Hittable.hits (Hittable.fs:27-31) -> Sphere.firstIntersection
-        const d2 g0 = sc.geo[pending * 3 + 0], g1 = sc.geo[pending * 3 + 1];
-        if (COUNT) cnt.prim++;
-        const double t = sphere_first_intersection(o, d, mk(g0.x, g0.y, g1.x), g1.y);
-        const double a = t * t;
-        if (a < bestF) { bestF = a; best = pending; bestLen = t; } // strict `<` on t^2 (Scene.fs:45-47); NaN fails
-    }
-    // UnboundedObjects, in array order, accepted only when Float.compare a bestFloat = Less (Scene.fs:77-86)
+    bp rec = sc.node + off;
+    const double vnx = *(dp) (rec + c.nX), vfx = *(dp) (rec + (c.nX ^ 8));
+    const double vny = *(dp) (rec + c.nY), vfy = *(dp) (rec + (c.nY ^ 8));
+    const double vnz = *(dp) (rec + c.nZ), vfz = *(dp) (rec + (c.nZ ^ 8));
+    const i2 lk = *(i2p) (rec + 48);
+    const bool hit = bbox_hits_nf(c.ix, c.iy, c.iz, o, vnx, vfx, vny, vfy, vnz, vfz);
+    off = hit ? off + RTD_NODE_BYTES : lk.x;
+    return (hit && lk.y >= 0) ? lk.y : -1;
+}
+// Leaf: Hittable.hits (Hittable.fs:27-31) -> Sphere.firstIntersection, kept if t^2 < bestFloat (strict; NaN fails)
+template <bool LDS>
+RTD_INLINE void leaf_test(const SceneView<LDS> &sc, V3 o, V3 d, int prim, WalkCtx &c, Walk &w) {
+    const d2 g0 = sc.geo[prim * 3 + 0], g1 = sc.geo[prim * 3 + 1];
+    const double t = sphere_first_intersection(o, d, mk(g0.x, g0.y, g1.x), g1.y);
+    const double a = t * t;
+    if (a < c.bestF) { c.bestF = a; w.best = prim; w.bestLen = t; }
+}
+// UnboundedObjects, in array order, accepted only when Float.compare a bestFloat = Less (Scene.fs:77-86)
+template <bool LDS, bool COUNT>
+RTD_INLINE void unbounded_tests(const SceneView<LDS> &sc, V3 o, V3 d, Walk &w, Counters &cnt) {
+    double bestF = (w.best < 0) ? __builtin_inf() : w.bestLen * w.bestLen;
     for (int u = 0; u < sc.n_unbounded; ++u) {
         int obj = sc.n_bounded + u;
         d2 g0 = sc.geo[obj * 3 + 0], g1 = sc.geo[obj * 3 + 1];
@@ -297,10 +306,34 @@ RTD_INLINE int hit_object(const SceneView<LDS> &sc, V3 o, V3 d, double &bestLen,
         } else t = sphere_first_intersection(o, d, mk(g0.x, g0.y, g1.x), g1.y);
         if (t == t) { // ValueSome
             double a = t * t;
-            if (fcmp(a, bestF) == CMP_LT) { bestF = a; best = obj; bestLen = t; }
+            if (fcmp(a, bestF) == CMP_LT) { bestF = a; w.best = obj; w.bestLen = t; }
         }
     }
-    return best;
+}
+
+// The whole of Scene.hitObject on one lane (unit hooks and trace_ray; the render kernel schedules the pieces itself).
+// Returns the object index or -1; `bestLen` is the ray parameter of the hit.
+template <bool LDS, bool COUNT>
+RTD_INLINE int hit_object(const SceneView<LDS> &sc, V3 o, V3 d, double &bestLen, Counters &cnt) {
+    if (COUNT) cnt.rays++;
+    Walk w;
+    walk_begin(w);
+    WalkCtx c = walk_ctx(d, w);
+    const int end = sc.n_nodes * RTD_NODE_BYTES;
+    for (;;) {
+        int pending = -1;
+        while (w.off < end) {
+            if (COUNT) cnt.aabb++;
+            pending = node_step<LDS>(sc, o, c, w.off);
+            if (pending >= 0) break;
+        }
+        if (pending < 0) break;
+        if (COUNT) cnt.prim++;
+        leaf_test<LDS>(sc, o, d, pending, c, w);
+    }
+    unbounded_tests<LDS, COUNT>(sc, o, d, w, cnt);
+    bestLen = w.bestLen;
+    return w.best;
 }
 
 // ---- Textures (Texture.fs:50-67, Sphere.planeMapInverse Sphere.fs:55-61) --------------------------------------------

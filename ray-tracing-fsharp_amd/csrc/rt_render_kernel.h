@@ -33,6 +33,8 @@ struct RenderParams {
     int32_t n_rows;
     int32_t k;                     // firstTrial = min 5 (spp/2)   (Scene.fs:172)
     int32_t chunk;                 // pixels per work unit, <= 64
+    int32_t yield_lanes;           // see run_items: stage yield threshold
+    int32_t refill_lanes;          // see run_items: refill threshold
     int32_t *accum;                // [n_rows*cols][4]
     uint8_t *rgb;                  // [n_rows*cols][3] or null
     unsigned long long *counters;  // [8]: rays, aabb, prim, refl, samples, pixels_early
@@ -80,25 +82,43 @@ template <> RTD_INLINE SceneView<false> make_view<false>(const RenderParams &p, 
     return v;
 }
 
+// Scheduling thresholds of run_items (lanes of a wave):
+//   yield_lanes  the node loop yields once this many lanes are waiting for another stage (a pending leaf test, or a finished
+//              walk that wants shading); the shade stage runs once this many walks are finished (or none is left walking)
+//   refill_lanes idle lanes are given new (pixel, sample) items once this many are idle (or nothing else is runnable)
+#define RTD_YIELD_DEFAULT 48
+#define RTD_REFILL_DEFAULT 8
+
 // Trace `total` items of the current unit.  Item i belongs to pixel slot map[i / per] (or i / per when map is null)
 // and is sample s_base + i % per of that pixel; its colour is added to accumulator slot (sample < split ? 0 : 1).
+//
+// Every lane is a path slot in one of three states: IDLE (wants a new item), WALK (somewhere in the tree walk of its
+// current ray; the walk state survives while the lane is parked), DONE (tree exhausted: wants the unbounded-object tests
+// and Hittable.Reflection).  Per-ray work is heavy-tailed (tree nodes per ray: mean 26, p99 60, max 150), so running
+// each stage until its slowest lane finishes leaves ~70 % of the lanes idle.  Instead a stage runs while enough lanes
+// want it and yields to the stage that has collected the most waiting lanes; a ray with a long walk simply stays in WALK
+// across several rounds.  Which lane computes what when has no effect on any result (streams are per item).
 template <bool LDS, bool COUNT>
 RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_AS3 uint32_t *acc, const RTD_AS3 uint32_t *pix,
                           const RTD_AS3 uint32_t *live, bool use_live, uint32_t total, uint32_t per, uint32_t s_base,
                           uint32_t split, Counters &cnt) {
-    bool alive = false;
+    enum { IDLE = 0, WALK = 1, DONE = 2 };
+    int st = IDLE;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
+    Walk w; walk_begin(w);
     Rng rng; rng.x = rng.y = rng.z = rng.w = 0;
     uint32_t colour = 0, slotOff = 0;
     int bounces = 0;
     uint32_t next = 0; // wave-uniform
+    const int end = sc.n_nodes * RTD_NODE_BYTES;
     for (;;) {
-        // ---- refill: idle lanes take the next items of the unit ----
-        unsigned long long need = __ballot(!alive);
-        if (need != 0ull && next < total) {
-            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) need, 0u));
+        // ---- refill: idle lanes take the next items of the unit (Scene.traceOnce's ray, Scene.fs:129-150) ----
+        const unsigned long long idle = __ballot(st == IDLE);
+        const unsigned long long busy = ~idle;
+        if (idle != 0ull && next < total && (__popcll(idle) >= p.refill_lanes || busy == 0ull)) {
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
             uint32_t item = next + rank;
-            if (!alive && item < total) {
+            if (st == IDLE && item < total) {
                 uint32_t j = item / per;
                 uint32_t s = s_base + (item - j * per);
                 uint32_t slot = use_live ? live[j] : j;
@@ -108,27 +128,57 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
                 slotOff = ((s < split) ? 0u : (uint32_t) p.chunk * 3u) + slot * 3u;
                 colour = RTD_WHITE;
                 bounces = 0;
-                if (camera_ray(p.cam, row, col, rng, o, d)) alive = true;
+                if (camera_ray(p.cam, row, col, rng, o, d)) {
+                    st = WALK;
+                    walk_begin(w);
+                    if (COUNT) cnt.rays++;
+                }
                 // else: Scene.fs:144's ValueOption.get would throw; the sample counts as Black (adds nothing)
             }
-            next += (uint32_t) __popcll(need);
+            next += (uint32_t) __popcll(idle);
             next = __builtin_amdgcn_readfirstlane(next);
         }
-        if (__ballot(alive) == 0ull) {
+        if (__ballot(st != IDLE) == 0ull) {
             if (next >= total) break;
             continue;
         }
-        // ---- one bounce of Scene.traceRay (Scene.fs:98-112) for every live lane ----
-        if (alive) {
-            double t;
-            int obj = hit_object<LDS, COUNT>(sc, o, d, t, cnt);
+
+        // ---- walk: BoundingBox.hits over the tree image, leaf tests deferred out of the node loop ----
+        if (__ballot(st == WALK) != 0ull) {
+            WalkCtx c = walk_ctx(d, w); // cheap to re-derive; keeps 9 doubles out of the parked state
+            for (;;) {
+                int pending = -1;
+                for (;;) {
+                    const bool act = (st == WALK) && (pending < 0) && (w.off < end);
+                    const int nAct = __popcll(__ballot(act));
+                    const int nWait = __popcll(__ballot((st == DONE) || ((st == WALK) && !act)));
+                    if (nAct == 0 || nWait >= p.yield_lanes) break;
+                    if (act) {
+                        if (COUNT) cnt.aabb++;
+                        pending = node_step<LDS>(sc, o, c, w.off);
+                    }
+                }
+                if (pending >= 0) {
+                    if (COUNT) cnt.prim++;
+                    leaf_test<LDS>(sc, o, d, pending, c, w);
+                }
+                if (st == WALK && w.off >= end) st = DONE;
+                const int nWalk = __popcll(__ballot(st == WALK));
+                const int nDone = __popcll(__ballot(st == DONE));
+                if (nWalk == 0 || nDone >= p.yield_lanes) break;
+            }
+        }
+
+        // ---- finish: the rest of Scene.hitObject, then Hittable.Reflection (Scene.fs:77-112) ----
+        if (st == DONE) {
+            unbounded_tests<LDS, COUNT>(sc, o, d, w, cnt);
             bool done = false;
             uint32_t result = RTD_BLACK;
-            if (obj < 0) done = true; // "never heard from again": Black
+            if (w.best < 0) done = true; // "never heard from again": Black
             else {
-                V3 strike = walk(o, d, t); // Ray.walkAlong ray bestLength (Scene.fs:91)
+                V3 strike = walk(o, d, w.bestLen); // Ray.walkAlong ray bestLength (Scene.fs:91)
                 if (COUNT) cnt.refl++;
-                if (reflection<LDS>(sc, obj, strike, o, d, colour, rng)) { done = true; result = colour; }
+                if (reflection<LDS>(sc, w.best, strike, o, d, colour, rng)) { done = true; result = colour; }
                 else {
                     bounces = bounces + 1;
                     if (bounces > p.cam.depth) { done = true; result = RTD_HOTPINK; } // Scene.fs:98,114
@@ -140,7 +190,11 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
                     lds_add(acc + slotOff + 1, (result >> 8) & 0xFFu);
                     lds_add(acc + slotOff + 2, (result >> 16) & 0xFFu);
                 }
-                alive = false;
+                st = IDLE;
+            } else {
+                st = WALK;
+                walk_begin(w);
+                if (COUNT) cnt.rays++;
             }
         }
     }

@@ -63,7 +63,7 @@ struct rt_scene {
     std::mutex mu;
 };
 
-static int g_block_threads = 0, g_chunk_pixels = 0, g_blocks_per_cu = 0;
+static int g_block_threads = 0, g_chunk_pixels = 0, g_blocks_per_cu = 0, g_yield_lanes = 0, g_refill_lanes = 0;
 
 static int device_scene(rt_scene *s, int device, DeviceScene **out) {
     std::lock_guard<std::mutex> lock(s->mu);
@@ -106,6 +106,10 @@ static render_fn pick_kernel(bool lds, bool count, int block) {
         if (lds) return count ? render_kernel<true, true, 1024> : render_kernel<true, false, 1024>;
         return count ? render_kernel<false, true, 1024> : render_kernel<false, false, 1024>;
     }
+    if (block == 768) {
+        if (lds) return count ? render_kernel<true, true, 768> : render_kernel<true, false, 768>;
+        return count ? render_kernel<false, true, 768> : render_kernel<false, false, 768>;
+    }
     if (block == 512) {
         if (lds) return count ? render_kernel<true, true, 512> : render_kernel<true, false, 512>;
         return count ? render_kernel<false, true, 512> : render_kernel<false, false, 512>;
@@ -132,13 +136,20 @@ size_t rt_abi_sizeof(int which) {
 }
 
 int rt_set_launch_config(int32_t block_threads, int32_t chunk_pixels, int32_t blocks_per_cu) {
-    if (block_threads != 0 && block_threads != 256 && block_threads != 512 && block_threads != 1024)
-        return fail(RT_ERR_INVALID_ARGUMENT, "block_threads must be 0, 256, 512 or 1024");
+    if (block_threads != 0 && block_threads != 256 && block_threads != 512 && block_threads != 768 && block_threads != 1024)
+        return fail(RT_ERR_INVALID_ARGUMENT, "block_threads must be 0, 256, 512, 768 or 1024");
     if (chunk_pixels < 0 || chunk_pixels > RTD_MAX_CHUNK) return fail(RT_ERR_INVALID_ARGUMENT, "chunk_pixels must be in [0, 64]");
     if (blocks_per_cu < 0 || blocks_per_cu > 8) return fail(RT_ERR_INVALID_ARGUMENT, "blocks_per_cu must be in [0, 8]");
     g_block_threads = block_threads;
     g_chunk_pixels = chunk_pixels;
     g_blocks_per_cu = blocks_per_cu;
+    return RT_OK;
+}
+
+int rt_set_schedule(int32_t yield_lanes, int32_t refill_lanes) {
+    if (yield_lanes < 0 || yield_lanes > 64 || refill_lanes < 0 || refill_lanes > 64) return fail(RT_ERR_INVALID_ARGUMENT, "thresholds must be in [0, 64]");
+    g_yield_lanes = yield_lanes;
+    g_refill_lanes = refill_lanes;
     return RT_OK;
 }
 
@@ -255,6 +266,8 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     const int half = camera->samples_per_pixel / 2;
     p.k = half < 5 ? half : 5; // min 5 (spp / 2), Scene.fs:172
     p.chunk = chunk;
+    p.yield_lanes = g_yield_lanes ? g_yield_lanes : RTD_YIELD_DEFAULT;
+    p.refill_lanes = g_refill_lanes ? g_refill_lanes : RTD_REFILL_DEFAULT;
     p.accum = (int32_t *) d_accum;
     p.rgb = (uint8_t *) d_rgb;
     unsigned slot;

@@ -12,9 +12,10 @@ ARGS="$*"
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 run sq2 SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVES SQ_INSTS_VALU_FMA_F64
 run sq3 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH
+run ic SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH
 run fetch FETCH_SIZE GRBM_GUI_ACTIVE
 run write WRITE_SIZE
-for d in sq1 sq2 sq3 fetch write; do f=$(ls $OUT/$d/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python - "$f" <<'PY'
+for d in sq1 sq2 sq3 ic fetch write; do f=$(ls $OUT/$d/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python - "$f" <<'PY'
 import csv, sys, collections
 acc = collections.defaultdict(float)
 for r in csv.DictReader(open(sys.argv[1])):

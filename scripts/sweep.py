@@ -25,12 +25,13 @@ scene = rt.Scene.make(objs)
 rows, cols = 2 * h + 1, 2 * w + 1
 dev = torch.device("cuda", 0)
 local = torch.zeros((rows, cols, 4), dtype=torch.int32, device=dev)
-cfgs = [tuple(int(x) for x in c.split(":")) + (0,) * (3 - len(c.split(":"))) for c in args.configs]
+cfgs = [tuple(int(x) for x in c.split(":")) + (0,) * (5 - len(c.split(":"))) for c in args.configs]  # block:chunk:bpc:yield:refill
 times = {c: [] for c in cfgs}
 ref = None
 for r in range(args.rounds + 1):
     for c in cfgs:
-        rt.set_launch_config(*c)
+        rt.set_launch_config(*c[:3])
+        rt.set_schedule(c[3], c[4])
         st = rtd.render_shard_device(scene, cam, w, h, 2024, 0, 0, 1, rows, local, counters=args.counters, want_stats=True)
         if r == 0:  # warm-up round doubles as a cross-config equality check
             cur = local.clone()
@@ -42,4 +43,4 @@ for r in range(args.rounds + 1):
             times[c].append(st["kernel_ms"])
 for c in cfgs:
     t = times[c]
-    print(f"block={c[0]:5d} chunk={c[1]:3d} bpc={c[2]}  median {statistics.median(t):9.3f} ms  min {min(t):9.3f}  max {max(t):9.3f}")
+    print(f"block={c[0]:5d} chunk={c[1]:3d} bpc={c[2]} yield={c[3]:2d} refill={c[4]:2d}  median {statistics.median(t):9.3f} ms  min {min(t):9.3f}  max {max(t):9.3f}")
