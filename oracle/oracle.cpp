@@ -111,11 +111,11 @@ static inline uint64_t mix64(uint64_t z) { // SplitMix64 finaliser
     return z;
 }
 static inline FloatProducer streamFor(uint64_t seed, uint64_t pixel, uint32_t sample) {
-    uint64_t h = mix64(seed + 0x9E3779B97F4A7C15ull);
-    h = mix64(h ^ (pixel * 0xD1B54A32D192ED03ull + 0x8CB92BA72F3D8DD7ull));
-    h = mix64(h ^ ((uint64_t) sample * 0xAEF17502108EF2D9ull + 0x2545F4914F6CDD1Dull));
-    uint64_t a = mix64(h + 0x9E3779B97F4A7C15ull);
-    uint64_t b = mix64(h + 2ull * 0x9E3779B97F4A7C15ull);
+    const uint64_t G = 0x9E3779B97F4A7C15ull;
+    uint64_t k = mix64(seed + G);                                                   // seed key
+    uint64_t hp = mix64(k ^ (pixel * 0xD1B54A32D192ED03ull + 0x8CB92BA72F3D8DD7ull)); // the pixel's SplitMix64 state
+    uint64_t a = mix64(hp + (2ull * sample + 1ull) * G);                            // its outputs 2s+1 and 2s+2
+    uint64_t b = mix64(hp + (2ull * sample + 2ull) * G);
     FloatProducer p;
     // uint (rand.Next ()) lies in [0, 2^31-2] (Float.fs:33-36): keep the state inside the reference's domain.
     p.x = (uint32_t) (a & 0xFFFFFFFFull) % 2147483647u;

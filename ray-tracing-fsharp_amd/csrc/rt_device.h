@@ -59,11 +59,19 @@ RTD_INLINE uint32_t rng_next(Rng &r) { // generateInt32, Float.fs:14-20
     r.w = r.w ^ (r.w >> 19) ^ (t ^ (t >> 8));
     return r.w;
 }
-// toInt is a byte reversal (Float.fs:22-27); toDouble divides by UInt32.MaxValue (Float.fs:29)
-RTD_INLINE double rng_get(Rng &r) { return (double) __builtin_bswap32(rng_next(r)) / 4294967295.0; }
+// toInt is a byte reversal (Float.fs:22-27); toDouble divides by UInt32.MaxValue (Float.fs:29).
+// The division is replaced by an identity: for every uint32 u, u / 4294967295.0 == fma(u, 2^-64 + 2^-96, u * 2^-32)
+// bit for bit (u/(2^32-1) = u*2^-32*(1 + 2^-32 + 2^-64 + ...); the fma carries the first three terms exactly and rounds
+// once, and the remaining tail can never reach a rounding boundary).  Checked EXHAUSTIVELY over all 2^32 inputs by
+// tests/test_rng_division_identity.py; the oracle keeps the literal division.
+RTD_INLINE double rng_get(Rng &r) {
+    const double x = (double) __builtin_bswap32(rng_next(r));
+    return fma(x, 0x1p-64 + 0x1p-96, x * 0x1p-32);
+}
 
-// Stream seeding (DESIGN.md "Seeding"): SplitMix64-finalised key of (seed, pixel, sample).
-__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) { // integer-only: also used by the host to derive the seed key
+// Stream seeding (DESIGN.md "Seeding"): every pixel owns a SplitMix64 sequence keyed by (seed, global pixel index); sample
+// s of the pixel takes outputs 2s+1 and 2s+2 of it as the four xorshift128 words.
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) { // SplitMix64 finaliser; integer-only, also used by the host
     z ^= z >> 30;
     z *= 0xBF58476D1CE4E5B9ull;
     z ^= z >> 27;
@@ -71,12 +79,11 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) { // integer-only
     z ^= z >> 31;
     return z;
 }
-RTD_INLINE uint64_t seed_key(uint64_t seed) { return mix64(seed + 0x9E3779B97F4A7C15ull); }
-RTD_INLINE Rng stream_for(uint64_t seedKey, uint64_t pixel, uint32_t sample) {
-    uint64_t h = mix64(seedKey ^ (pixel * 0xD1B54A32D192ED03ull + 0x8CB92BA72F3D8DD7ull));
-    h = mix64(h ^ ((uint64_t) sample * 0xAEF17502108EF2D9ull + 0x2545F4914F6CDD1Dull));
-    uint64_t a = mix64(h + 0x9E3779B97F4A7C15ull);
-    uint64_t b = mix64(h + 2ull * 0x9E3779B97F4A7C15ull);
+#define RTD_GOLDEN 0x9E3779B97F4A7C15ull
+RTD_INLINE uint64_t pixel_key(uint64_t seedKey, uint64_t pixel) { return mix64(seedKey ^ (pixel * 0xD1B54A32D192ED03ull + 0x8CB92BA72F3D8DD7ull)); }
+RTD_INLINE Rng stream_for(uint64_t pixelKey, uint32_t sample) {
+    const uint64_t a = mix64(pixelKey + (2ull * sample + 1ull) * RTD_GOLDEN);
+    const uint64_t b = mix64(pixelKey + (2ull * sample + 2ull) * RTD_GOLDEN);
     Rng r;
     r.x = (uint32_t) (a & 0xFFFFFFFFull) % 2147483647u; // uint (rand.Next ()) < 2^31-1 (Float.fs:33-36)
     r.y = (uint32_t) (a >> 32) % 2147483647u;
@@ -456,20 +463,24 @@ RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, 
         haveV2 = unitise(vsub(d, vscale(coefficient, n)), v2);
     }
 
+    // The three geometric stages below each end in "unitise (target - strike) and overwrite the ray"; they only PREPARE
+    // the vector, one shared normalisation follows.  `originToStrike` covers the one asymmetry: a failed overwriteWithMake
+    // leaves a sphere's ray untouched (Ray.fs:14-15), whereas the plane's pureOutgoing builds a new ray at the strike point.
+    V3 nv = mk(0.0, 0.0, 0.0);
+    bool haveNv = false, originToStrike = false;
+
     if (act & ACT_REFRACT) { // Sphere.refract (Sphere.fs:108-146)
         double index = inside ? 1.0 / ior : ior / 1.0;
-        if (!haveV2) { // parallel to the normal: straight through (re-normalised, Sphere.fs:121-124)
-            V3 nd;
-            if (unitise(d, nd)) { o = strike; d = nd; }
-        } else {
+        if (!haveV2) { nv = d; haveNv = true; } // parallel to the normal: straight through, re-normalised (Sphere.fs:121-124)
+        else {
             double sinI = sqrt(1.0 - cosI * cosI);
             double sinO = sinI / index;
             if (fcmp(sinO, 1.0) == CMP_GT) act |= ACT_REFLECT; // total internal reflection (Sphere.fs:130-132)
             else {
                 double cosO = sqrt(1.0 - sinO * sinO);
                 V3 outP = walk(walk(strike, n, (-cosO)), v2, sinO);
-                V3 nd;
-                if (unitise(vsub(outP, strike), nd)) { o = strike; d = nd; }
+                nv = vsub(outP, strike);
+                haveNv = true;
             }
         }
     }
@@ -482,28 +493,29 @@ RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, 
             double nC = -dot(n, d);
             double tC = dot(v2, d);
             V3 dest = walk(walk(strike, n, nC), v2, tC);
-            V3 nd;
-            bool ok = unitise(vsub(dest, strike), nd);
-            if (ok) d = nd;
-            if (ok || isPlane) o = strike; // a failed overwriteWithMake leaves a sphere's ray untouched (Ray.fs:14-15)
+            nv = vsub(dest, strike);
+            haveNv = true;
+            originToStrike = isPlane;
         }
     }
 
-    if (act & ACT_FUZZ) { // Sphere.addFuzz (Sphere.fs:89-104) / InfinitePlane.fs:63-71
-        for (;;) {
-            V3 offset = random_unit(rng);
-            V3 centre = walk(o, d, 1.0);
-            V3 target = walk(centre, offset, fuzz);
-            V3 nd;
-            if (unitise(vsub(target, strike), nd)) { o = strike; d = nd; break; }
-        }
+    if (haveNv) {
+        V3 nd;
+        bool ok = unitise(nv, nd);
+        if (ok) d = nd;
+        if (ok || originToStrike) o = strike;
     }
 
-    if (act & (ACT_LAMBERT | ACT_LAMBERT_ONCE)) { // Sphere.fs:211-220 (retry) / InfinitePlane.fs:79-86 (single try)
-        V3 centre = walk(strike, n, 1.0);
+    // Sphere.addFuzz (Sphere.fs:89-104) / InfinitePlane.fs:63-71: unit offset scaled by fuzz around (ray.origin + ray.dir);
+    // Lambert, Sphere.fs:211-220 (retry) / InfinitePlane.fs:79-86 (single try): unit offset around (strike + normal).
+    // Same arithmetic shape -- centre = base + dir*1.0, target = centre + offset*scale -- so one loop serves both.
+    if (act & (ACT_FUZZ | ACT_LAMBERT | ACT_LAMBERT_ONCE)) {
+        const bool fz = (act & ACT_FUZZ) != 0;
+        const V3 centre = fz ? walk(o, d, 1.0) : walk(strike, n, 1.0);
+        const double scale = fz ? fuzz : 1.0;
         for (;;) {
             V3 offset = random_unit(rng);
-            V3 target = walk(centre, offset, 1.0);
+            V3 target = walk(centre, offset, scale);
             V3 nd;
             if (unitise(vsub(target, strike), nd)) { o = strike; d = nd; break; }
             if (act & ACT_LAMBERT_ONCE) { colour = RTD_BLACK; return true; } // the reference throws here; see DESIGN.md

@@ -43,7 +43,7 @@ struct RenderParams {
 
 // Per-wave LDS scratch (in 4-byte words), P = pixels per work unit:
 //   acc  [2][P][3]  sums of slot 0 / slot 1
-//   pix  [P][4]     row, col, pixel index lo, hi
+//   pix  [P][4]     row, col, pixel stream key lo, hi
 //   live [P]        compacted pixel slots for phase 2
 #define RTD_WAVE_WORDS(P) (11u * (uint32_t) (P))
 
@@ -113,7 +113,7 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
     const int end = sc.n_nodes * RTD_NODE_BYTES;
     for (;;) {
         // ---- refill: idle lanes take the next items of the unit (Scene.traceOnce's ray, Scene.fs:129-150) ----
-        const unsigned long long idle = __ballot(st == IDLE);
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(st == IDLE);
         const unsigned long long busy = ~idle;
         if (idle != 0ull && next < total && (__popcll(idle) >= p.refill_lanes || busy == 0ull)) {
             uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
@@ -123,8 +123,8 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
                 uint32_t s = s_base + (item - j * per);
                 uint32_t slot = use_live ? live[j] : j;
                 int row = (int) pix[slot * 4 + 0], col = (int) pix[slot * 4 + 1];
-                uint64_t pixel = (uint64_t) pix[slot * 4 + 2] | ((uint64_t) pix[slot * 4 + 3] << 32);
-                rng = stream_for(p.seed_key, pixel, s);
+                uint64_t pkey = (uint64_t) pix[slot * 4 + 2] | ((uint64_t) pix[slot * 4 + 3] << 32);
+                rng = stream_for(pkey, s);
                 slotOff = ((s < split) ? 0u : (uint32_t) p.chunk * 3u) + slot * 3u;
                 colour = RTD_WHITE;
                 bounces = 0;
@@ -138,20 +138,20 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
             next += (uint32_t) __popcll(idle);
             next = __builtin_amdgcn_readfirstlane(next);
         }
-        if (__ballot(st != IDLE) == 0ull) {
+        if (__builtin_amdgcn_ballot_w64(st != IDLE) == 0ull) {
             if (next >= total) break;
             continue;
         }
 
         // ---- walk: BoundingBox.hits over the tree image, leaf tests deferred out of the node loop ----
-        if (__ballot(st == WALK) != 0ull) {
+        if (__builtin_amdgcn_ballot_w64(st == WALK) != 0ull) {
             WalkCtx c = walk_ctx(d, w); // cheap to re-derive; keeps 9 doubles out of the parked state
             for (;;) {
                 int pending = -1;
                 for (;;) {
                     const bool act = (st == WALK) && (pending < 0) && (w.off < end);
-                    const int nAct = __popcll(__ballot(act));
-                    const int nWait = __popcll(__ballot((st == DONE) || ((st == WALK) && !act)));
+                    const int nAct = __popcll(__builtin_amdgcn_ballot_w64(act));
+                    const int nWait = __popcll(__builtin_amdgcn_ballot_w64((st == DONE) || ((st == WALK) && !act)));
                     if (nAct == 0 || nWait >= p.yield_lanes) break;
                     if (act) {
                         if (COUNT) cnt.aabb++;
@@ -163,8 +163,8 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
                     leaf_test<LDS>(sc, o, d, pending, c, w);
                 }
                 if (st == WALK && w.off >= end) st = DONE;
-                const int nWalk = __popcll(__ballot(st == WALK));
-                const int nDone = __popcll(__ballot(st == DONE));
+                const int nWalk = __popcll(__builtin_amdgcn_ballot_w64(st == WALK));
+                const int nDone = __popcll(__builtin_amdgcn_ballot_w64(st == DONE));
                 if (nWalk == 0 || nDone >= p.yield_lanes) break;
             }
         }
@@ -245,11 +245,11 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
             uint32_t lr = (uint32_t) (lp / (uint64_t) p.cols);
             uint32_t c = (uint32_t) (lp - (uint64_t) lr * (uint64_t) p.cols);
             uint32_t r = (uint32_t) p.row_first + lr * (uint32_t) p.row_stride;
-            uint64_t pixel = (uint64_t) r * (uint64_t) p.cols + c;
+            uint64_t pkey = pixel_key(p.seed_key, (uint64_t) r * (uint64_t) p.cols + c); // global pixel index
             pix[lane * 4 + 0] = (uint32_t) (p.cam.max_h - (int) r - 1);
             pix[lane * 4 + 1] = (uint32_t) ((int) c - p.cam.max_w);
-            pix[lane * 4 + 2] = (uint32_t) pixel;
-            pix[lane * 4 + 3] = (uint32_t) (pixel >> 32);
+            pix[lane * 4 + 2] = (uint32_t) pkey;
+            pix[lane * 4 + 3] = (uint32_t) (pkey >> 32);
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
             if (diff == 0) earlyCount++;
             cont = (diff != 0) && (n2 > 0u);
         }
-        unsigned long long liveMask = __ballot(cont);
+        unsigned long long liveMask = __builtin_amdgcn_ballot_w64(cont);
         uint32_t nLive = (uint32_t) __popcll(liveMask);
         if (cont) {
             uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (liveMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) liveMask, 0u));

@@ -401,7 +401,7 @@ __global__ void k_float_producer(Rng r, int n, double *out) {
 __global__ void k_stream_state(uint64_t seedKey, int n, const uint64_t *pixel, const uint32_t *sample, uint32_t *out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Rng r = stream_for(seedKey, pixel[i], sample[i]);
+    Rng r = stream_for(pixel_key(seedKey, pixel[i]), sample[i]);
     out[i * 4] = r.x; out[i * 4 + 1] = r.y; out[i * 4 + 2] = r.z; out[i * 4 + 3] = r.w;
 }
 __global__ void k_bbox_hits(int n, const double *rays, const double *boxes, int32_t *hit) {
