@@ -139,15 +139,17 @@ RTD_INLINE double pow5(double x) {
 
 // ---- flattened scene ------------------------------------------------------------------------------------
 // Image layout (bytes; every section 16-byte aligned; built by rt_scene.h, staged verbatim into LDS):
-//   node [n_nodes]   56 B  {lo_x, hi_x, lo_y, hi_y, lo_z, hi_z : double; skip_off, prim : int32}
-//                          skip_off = BYTE offset of the node to visit when this box is missed (n_nodes*56 = end);
-//                          prim = object index of a Leaf, -1 for a Branch.  7 x ds_read_b64 per visit; a 56-B stride
-//                          spreads consecutive records over all 32 eight-byte LDS slots (7 is odd).
+//   node [n_nodes]   56 B  {lo_x, hi_x, lo_y, hi_y, lo_z, hi_z : double; on_hit, on_miss : int32}
+//                          on_miss = BYTE offset of the node to visit when this box is missed (n_nodes*56 = end);
+//                          on_hit  = byte offset of the next record for a Branch, RTD_LEAF|object index for a Leaf (whose
+//                          successor is on_miss either way).  7 x ds_read_b64 per visit; a 56-B stride spreads
+//                          consecutive records over all 32 eight-byte LDS slots (7 is odd).
 //   geo  [n_obj][3]  d2    sphere {cx,cy}{cz,r^2}{radius,0} | plane {px,py}{pz,nx}{ny,nz}   48 B/object
 //   meta [n_obj]     i2    {kind|style<<2|flipped<<5, rgb|(texture+1)<<24}                   8 B/object
 //   mat  [n_obj][3]  double {albedo, fuzz|ior, prob}                                       24 B/object
 // Objects: bounded spheres first (tree leaves point at them), then the unbounded list in Scene.make order.
 #define RTD_NODE_BYTES 56
+#define RTD_LEAF 0x40000000 /* flag in on_hit / in a walk offset: a leaf's primitive test is pending */
 struct TexRec { // global memory only
     uint32_t kind;
     uint32_t rgb;       // packed colour
@@ -256,7 +258,9 @@ RTD_INLINE double plane_intersection(V3 o, V3 d, V3 p0, V3 n) {
 // from the ray each time a lane (re)enters the node loop.  The order in which a ray sees its leaves never changes, so the
 // strict-`<` tie-breaking of Scene.fs:45-47 is unchanged.
 struct Walk {
-    int off;        // byte offset of the next node record; >= n_nodes*56 when the tree is exhausted
+    int off;        // byte offset of the next node record; >= n_nodes*56 when the tree is exhausted or the lane is not walking;
+                    // RTD_LEAF|object while that leaf's primitive test is pending (then `resume` is where the walk continues)
+    int resume;
     int best;       // bestObject (object index) or -1
     double bestLen; // bestLength; NaN until something is hit (Scene.fs:64)
 };
@@ -265,7 +269,7 @@ struct WalkCtx {
     int nX, nY, nZ;    // byte offset of each axis' NEAR plane inside a node record: the swap of BoundingBox.fs:52-55
     double bestF;      // bestFloat = bestLength^2, +inf until something is hit (Scene.fs:65)
 };
-RTD_INLINE void walk_begin(Walk &w) { w.off = 0; w.best = -1; w.bestLen = __builtin_nan(""); }
+RTD_INLINE void walk_begin(Walk &w) { w.off = 0; w.resume = 0; w.best = -1; w.bestLen = __builtin_nan(""); }
 RTD_INLINE WalkCtx walk_ctx(V3 d, const Walk &w) {
     WalkCtx c;
     c.ix = 1.0 / d.x; c.iy = 1.0 / d.y; c.iz = 1.0 / d.z;
@@ -273,29 +277,30 @@ RTD_INLINE WalkCtx walk_ctx(V3 d, const Walk &w) {
     c.bestF = (w.best < 0) ? __builtin_inf() : w.bestLen * w.bestLen; // `a = point * point` (Scene.fs:45), recomputed
     return c;
 }
-// One BoundingBox.hits + advance.  Returns the leaf's object index when a Leaf box was hit (its primitive test is then
-// pending), else -1.
+// One BoundingBox.hits + advance: w.off becomes on_hit or on_miss; a hit Leaf leaves RTD_LEAF|object there.
 template <bool LDS>
-RTD_INLINE int node_step(const SceneView<LDS> &sc, V3 o, const WalkCtx &c, int &off) {
+RTD_INLINE void node_step(const SceneView<LDS> &sc, V3 o, const WalkCtx &c, Walk &w) {
     typedef typename Ptrs<LDS>::bp bp;
     typedef typename Ptrs<LDS>::dp dp;
     typedef typename Ptrs<LDS>::i2p i2p;
-    bp rec = sc.node + off;
+    bp rec = sc.node + w.off;
     const double vnx = *(dp) (rec + c.nX), vfx = *(dp) (rec + (c.nX ^ 8));
     const double vny = *(dp) (rec + c.nY), vfy = *(dp) (rec + (c.nY ^ 8));
     const double vnz = *(dp) (rec + c.nZ), vfz = *(dp) (rec + (c.nZ ^ 8));
     const i2 lk = *(i2p) (rec + 48);
     const bool hit = bbox_hits_nf(c.ix, c.iy, c.iz, o, vnx, vfx, vny, vfy, vnz, vfz);
-    off = hit ? off + RTD_NODE_BYTES : lk.x;
-    return (hit && lk.y >= 0) ? lk.y : -1;
+    w.off = hit ? lk.x : lk.y;
+    w.resume = lk.y;
 }
 // Leaf: Hittable.hits (Hittable.fs:27-31) -> Sphere.firstIntersection, kept if t^2 < bestFloat (strict; NaN fails)
 template <bool LDS>
-RTD_INLINE void leaf_test(const SceneView<LDS> &sc, V3 o, V3 d, int prim, WalkCtx &c, Walk &w) {
+RTD_INLINE void leaf_test(const SceneView<LDS> &sc, V3 o, V3 d, WalkCtx &c, Walk &w) {
+    const int prim = w.off & (RTD_LEAF - 1);
     const d2 g0 = sc.geo[prim * 3 + 0], g1 = sc.geo[prim * 3 + 1];
     const double t = sphere_first_intersection(o, d, mk(g0.x, g0.y, g1.x), g1.y);
     const double a = t * t;
     if (a < c.bestF) { c.bestF = a; w.best = prim; w.bestLen = t; }
+    w.off = w.resume;
 }
 // UnboundedObjects, in array order, accepted only when Float.compare a bestFloat = Less (Scene.fs:77-86)
 template <bool LDS, bool COUNT>
@@ -328,15 +333,13 @@ RTD_INLINE int hit_object(const SceneView<LDS> &sc, V3 o, V3 d, double &bestLen,
     WalkCtx c = walk_ctx(d, w);
     const int end = sc.n_nodes * RTD_NODE_BYTES;
     for (;;) {
-        int pending = -1;
         while (w.off < end) {
             if (COUNT) cnt.aabb++;
-            pending = node_step<LDS>(sc, o, c, w.off);
-            if (pending >= 0) break;
+            node_step<LDS>(sc, o, c, w);
         }
-        if (pending < 0) break;
+        if (!(w.off & RTD_LEAF)) break;
         if (COUNT) cnt.prim++;
-        leaf_test<LDS>(sc, o, d, pending, c, w);
+        leaf_test<LDS>(sc, o, d, c, w);
     }
     unbounded_tests<LDS, COUNT>(sc, o, d, w, cnt);
     bestLen = w.bestLen;

@@ -105,12 +105,12 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
     enum { IDLE = 0, WALK = 1, DONE = 2 };
     int st = IDLE;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
-    Walk w; walk_begin(w);
+    const int end = sc.n_nodes * RTD_NODE_BYTES;
+    Walk w; walk_begin(w); w.off = end; // idle lanes are parked at `end`
     Rng rng; rng.x = rng.y = rng.z = rng.w = 0;
     uint32_t colour = 0, slotOff = 0;
     int bounces = 0;
     uint32_t next = 0; // wave-uniform
-    const int end = sc.n_nodes * RTD_NODE_BYTES;
     for (;;) {
         // ---- refill: idle lanes take the next items of the unit (Scene.traceOnce's ray, Scene.fs:129-150) ----
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(st == IDLE);
@@ -144,25 +144,28 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
         }
 
         // ---- walk: BoundingBox.hits over the tree image, leaf tests deferred out of the node loop ----
+        // A lane steps iff w.off < end: finished walks sit at >= end, pending leaves carry RTD_LEAF (> end), idle lanes are
+        // parked at `end`.  So one compare gives the active set, and waiting = busy - active.
+        const int nBusy = __popcll(__builtin_amdgcn_ballot_w64(st != IDLE));
         if (__builtin_amdgcn_ballot_w64(st == WALK) != 0ull) {
             WalkCtx c = walk_ctx(d, w); // cheap to re-derive; keeps 9 doubles out of the parked state
+            const int stop = (nBusy - p.yield_lanes) > 0 ? (nBusy - p.yield_lanes) : 0; // active <= stop  <=>  waiting >= yield
             for (;;) {
-                int pending = -1;
                 for (;;) {
-                    const bool act = (st == WALK) && (pending < 0) && (w.off < end);
+                    const bool act = w.off < end;
                     const int nAct = __popcll(__builtin_amdgcn_ballot_w64(act));
-                    const int nWait = __popcll(__builtin_amdgcn_ballot_w64((st == DONE) || ((st == WALK) && !act)));
-                    if (nAct == 0 || nWait >= p.yield_lanes) break;
+                    if (nAct <= stop) break;
                     if (act) {
                         if (COUNT) cnt.aabb++;
-                        pending = node_step<LDS>(sc, o, c, w.off);
+                        node_step<LDS>(sc, o, c, w);
                     }
                 }
-                if (pending >= 0) {
+                if (w.off & RTD_LEAF) {
                     if (COUNT) cnt.prim++;
-                    leaf_test<LDS>(sc, o, d, pending, c, w);
+                    leaf_test<LDS>(sc, o, d, c, w);
                 }
-                if (st == WALK && w.off >= end) st = DONE;
+                const bool fin = (st == WALK) && (w.off >= end);
+                if (fin) st = DONE;
                 const int nWalk = __popcll(__builtin_amdgcn_ballot_w64(st == WALK));
                 const int nDone = __popcll(__builtin_amdgcn_ballot_w64(st == DONE));
                 if (nWalk == 0 || nDone >= p.yield_lanes) break;
@@ -191,6 +194,7 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
                     lds_add(acc + slotOff + 2, (result >> 16) & 0xFFu);
                 }
                 st = IDLE;
+                w.off = end;
             } else {
                 st = WALK;
                 walk_begin(w);

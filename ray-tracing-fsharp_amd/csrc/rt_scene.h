@@ -209,8 +209,9 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
         double *bx = (double *) (pnode + i * RTD_NODE_BYTES);
         int32_t *lk = (int32_t *) (pnode + i * RTD_NODE_BYTES + 48);
         for (int a = 0; a < 3; ++a) { bx[a * 2] = s.tree.box[i].mn[a]; bx[a * 2 + 1] = s.tree.box[i].mx[a]; }
-        lk[0] = s.tree.skip[i] * RTD_NODE_BYTES; // byte offset of the record to visit on a miss
-        lk[1] = s.tree.prim[i];
+        const int32_t onMiss = s.tree.skip[i] * RTD_NODE_BYTES; // byte offset of the record to visit on a miss
+        lk[0] = s.tree.prim[i] >= 0 ? (int32_t) (RTD_LEAF | s.tree.prim[i]) : (int32_t) ((i + 1) * RTD_NODE_BYTES); // on_hit
+        lk[1] = onMiss;
     }
     for (size_t j = 0; j < nobj; ++j) {
         const rt_hittable &o = h[(size_t) s.objToOrig[j]];
