@@ -205,15 +205,17 @@ struct Counters { uint32_t rays, aabb, prim, refl; };
 //  * With tMin/tMax never NaN, `not (tMax < tMin || 0.0 >= tMax)` is `tMax >= tMin && tMax > 0.0`; tMin only rises and
 //    tMax only falls over the three axes, so the x- and y-stage tests are implied by the later ones except `tMax_y > 0`
 //    (the reference's asymmetry: bail-outs use `0.0 >= tMax`, the final test `tMax >= 0.0`).
+//  * The final `tMax >= 0.0` is folded into tMin's starting value: with tMin' = max(tMin, 0), `tMax >= tMin'` is
+//    `tMax >= tMin && tMax >= 0`.
 RTD_INLINE bool bbox_hits_nf(double ix, double iy, double iz, V3 o, double nx, double fx, double ny, double fy, double nz, double fz) {
-    double tMin = __builtin_fmax((nx - o.x) * ix, -__builtin_inf());
-    double tMax = __builtin_fmin((fx - o.x) * ix, __builtin_inf());
+    double tMin = __builtin_fmax((nx - o.x) * ix, 0.0);            // NaN (0 * inf) -> 0.0, exactly as -inf would end up
+    double tMax = __builtin_fmin((fx - o.x) * ix, __builtin_inf()); // NaN -> +inf
     tMin = __builtin_fmax((ny - o.y) * iy, tMin);
     tMax = __builtin_fmin((fy - o.y) * iy, tMax);
     const bool yPos = tMax > 0.0;
     tMin = __builtin_fmax((nz - o.z) * iz, tMin);
     tMax = __builtin_fmin((fz - o.z) * iz, tMax);
-    return (tMax >= tMin) & yPos & (tMax >= 0.0);
+    return (tMax >= tMin) & yPos;
 }
 // (min,max)-ordered operands, as the unit hook and the reference's tests hand them over
 RTD_INLINE bool bbox_hits(double ix, double iy, double iz, V3 o, d2 bx, d2 by, d2 bz) {

@@ -37,7 +37,8 @@ struct RenderParams {
     int32_t refill_lanes;          // see run_items: refill threshold
     int32_t *accum;                // [n_rows*cols][4]
     uint8_t *rgb;                  // [n_rows*cols][3] or null
-    unsigned long long *counters;  // [8]: rays, aabb, prim, refl, samples, pixels_early
+    unsigned long long *counters;  // [16]: rays, aabb, prim, refl, samples, pixels_early, -, -, then stage executions (COUNT):
+                                   //       [8] refill [9] node trips [10] leaf stages [11] shade stages [12] lanes refilled [13] lanes shaded
     unsigned int *queue;           // work-unit counter, zeroed before launch
 };
 
@@ -86,8 +87,10 @@ template <> RTD_INLINE SceneView<false> make_view<false>(const RenderParams &p, 
 //   yield_lanes  the node loop yields once this many lanes are waiting for another stage (a pending leaf test, or a finished
 //              walk that wants shading); the shade stage runs once this many walks are finished (or none is left walking)
 //   refill_lanes idle lanes are given new (pixel, sample) items once this many are idle (or nothing else is runnable)
-#define RTD_YIELD_DEFAULT 48
-#define RTD_REFILL_DEFAULT 8
+struct StageStats { uint32_t refill, trips, leaf, shade, refillLanes, shadeLanes; }; // wave-uniform, COUNT variant only
+
+#define RTD_YIELD_DEFAULT 44
+#define RTD_REFILL_DEFAULT 12
 
 // Trace `total` items of the current unit.  Item i belongs to pixel slot map[i / per] (or i / per when map is null)
 // and is sample s_base + i % per of that pixel; its colour is added to accumulator slot (sample < split ? 0 : 1).
@@ -101,7 +104,7 @@ template <> RTD_INLINE SceneView<false> make_view<false>(const RenderParams &p, 
 template <bool LDS, bool COUNT>
 RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_AS3 uint32_t *acc, const RTD_AS3 uint32_t *pix,
                           const RTD_AS3 uint32_t *live, bool use_live, uint32_t total, uint32_t per, uint32_t s_base,
-                          uint32_t split, Counters &cnt) {
+                          uint32_t split, Counters &cnt, StageStats &ss) {
     enum { IDLE = 0, WALK = 1, DONE = 2 };
     int st = IDLE;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
@@ -118,6 +121,7 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
         if (idle != 0ull && next < total && (__popcll(idle) >= p.refill_lanes || busy == 0ull)) {
             uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
             uint32_t item = next + rank;
+            if (COUNT) { ss.refill++; ss.refillLanes += (uint32_t) __popcll(idle); }
             if (st == IDLE && item < total) {
                 uint32_t j = item / per;
                 uint32_t s = s_base + (item - j * per);
@@ -155,11 +159,13 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
                     const bool act = w.off < end;
                     const int nAct = __popcll(__builtin_amdgcn_ballot_w64(act));
                     if (nAct <= stop) break;
+                    if (COUNT) ss.trips++;
                     if (act) {
                         if (COUNT) cnt.aabb++;
                         node_step<LDS>(sc, o, c, w);
                     }
                 }
+                if (COUNT && __builtin_amdgcn_ballot_w64((w.off & RTD_LEAF) != 0) != 0ull) ss.leaf++;
                 if (w.off & RTD_LEAF) {
                     if (COUNT) cnt.prim++;
                     leaf_test<LDS>(sc, o, d, c, w);
@@ -173,6 +179,7 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
         }
 
         // ---- finish: the rest of Scene.hitObject, then Hittable.Reflection (Scene.fs:77-112) ----
+        if (COUNT) { const unsigned long long dm = __builtin_amdgcn_ballot_w64(st == DONE); if (dm) { ss.shade++; ss.shadeLanes += (uint32_t) __popcll(dm); } }
         if (st == DONE) {
             unbounded_tests<LDS, COUNT>(sc, o, d, w, cnt);
             bool done = false;
@@ -231,6 +238,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     const uint32_t n2 = n2s > 0 ? (uint32_t) n2s : 0u;
 
     Counters cnt; cnt.rays = cnt.aabb = cnt.prim = cnt.refl = 0;
+    StageStats ss; ss.refill = ss.trips = ss.leaf = ss.shade = ss.refillLanes = ss.shadeLanes = 0;
     uint32_t earlyCount = 0;
     uint64_t sampleCount = 0; // Scene.traceOnce calls = sum of PixelStats.Count
 
@@ -258,7 +266,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
         __builtin_amdgcn_wave_barrier();
 
         // ---- phase 1: 2k+1 samples per pixel, sums split after sample k (Scene.fs:172-182) ----
-        run_items<LDS, COUNT>(p, sc, acc, pix, live, false, npx * n1, n1, 0u, k + 1u, cnt);
+        run_items<LDS, COUNT>(p, sc, acc, pix, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
         __builtin_amdgcn_wave_barrier();
 
         // ---- decide (Scene.fs:177-188) and compact the pixels that continue ----
@@ -288,7 +296,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
 
         // ---- phase 2: the remaining spp-2k-1 samples of the surviving pixels (Scene.fs:191-192) ----
         if (nLive > 0u) {
-            run_items<LDS, COUNT>(p, sc, acc, pix, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt);
+            run_items<LDS, COUNT>(p, sc, acc, pix, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
             __builtin_amdgcn_wave_barrier();
         }
 
@@ -322,6 +330,12 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
             atomicAdd(&p.counters[1], (unsigned long long) b);
             atomicAdd(&p.counters[2], (unsigned long long) c);
             atomicAdd(&p.counters[3], (unsigned long long) dd);
+            atomicAdd(&p.counters[8], (unsigned long long) ss.refill);
+            atomicAdd(&p.counters[9], (unsigned long long) ss.trips);
+            atomicAdd(&p.counters[10], (unsigned long long) ss.leaf);
+            atomicAdd(&p.counters[11], (unsigned long long) ss.shade);
+            atomicAdd(&p.counters[12], (unsigned long long) ss.refillLanes);
+            atomicAdd(&p.counters[13], (unsigned long long) ss.shadeLanes);
         }
     }
     if (lane == 0) {

@@ -50,12 +50,12 @@ struct DeviceScene {
     unsigned char *image = nullptr;
     TexRec *tex = nullptr;
     uint8_t *texels = nullptr;
-    unsigned char *scratch = nullptr; // ring of 128-byte {counters[8], queue} slots
+    unsigned char *scratch = nullptr; // ring of 256-byte {counters[16], queue} slots
     unsigned next_slot = 0;
     int cu_count = 0;
 };
 #define RT_SCRATCH_SLOTS 64
-#define RT_SCRATCH_BYTES 128
+#define RT_SCRATCH_BYTES 256
 
 struct rt_scene {
     rth::HostScene host;
@@ -63,6 +63,7 @@ struct rt_scene {
     std::mutex mu;
 };
 
+static unsigned long long g_last_stage_stats[6] = {0};
 static int g_block_threads = 0, g_chunk_pixels = 0, g_blocks_per_cu = 0, g_yield_lanes = 0, g_refill_lanes = 0;
 
 static int device_scene(rt_scene *s, int device, DeviceScene **out) {
@@ -143,6 +144,14 @@ int rt_set_launch_config(int32_t block_threads, int32_t chunk_pixels, int32_t bl
     g_block_threads = block_threads;
     g_chunk_pixels = chunk_pixels;
     g_blocks_per_cu = blocks_per_cu;
+    return RT_OK;
+}
+
+/* Diagnostic: wave-level stage executions of the last render with RT_RENDER_COUNTERS on this process:
+ * refill stages, node trips, leaf stages, shade stages, lanes refilled, lanes shaded. */
+int rt_last_stage_stats(uint64_t out[6]) {
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    for (int i = 0; i < 6; ++i) out[i] = g_last_stage_stats[i];
     return RT_OK;
 }
 
@@ -277,7 +286,7 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     }
     unsigned char *scr = ds->scratch + (size_t) slot * RT_SCRATCH_BYTES;
     p.counters = (unsigned long long *) scr;
-    p.queue = (unsigned int *) (scr + 64);
+    p.queue = (unsigned int *) (scr + 128);
 
     const size_t ldsBytes = (lds ? (size_t) h.off.total : 0u) + (size_t) (block / 64) * RTD_WAVE_WORDS(chunk) * 4u;
     render_fn fn = pick_kernel(lds, count, block);
@@ -307,8 +316,9 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     }
     if (stats) {
         HIP_TRY(hipStreamSynchronize(st));
-        unsigned long long c[8] = {0};
+        unsigned long long c[16] = {0};
         HIP_TRY(hipMemcpy(c, scr, sizeof(c), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 6; ++i) g_last_stage_stats[i] = c[8 + i];
         float ms = 0.f;
         if (grid > 0) HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         (void) hipEventDestroy(ev0);

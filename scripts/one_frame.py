@@ -27,3 +27,9 @@ local = torch.zeros((rows, cols, 4), dtype=torch.int32, device="cuda:0")
 for _ in range(a.launches):
     st = rtd.render_shard_device(scene, cam, w, h, 2024, 0, 0, 1, rows, local, counters=a.counters, want_stats=True)
     print({k: st[k] for k in ("kernel_ms", "rays", "aabb_tests", "prim_tests", "samples")}, flush=True)
+    if a.counters:
+        import ctypes
+        ss = (ctypes.c_uint64 * 6)()
+        rt.lib.rt_last_stage_stats(ss)
+        names = ("refill_stages", "node_trips", "leaf_stages", "shade_stages", "lanes_refilled", "lanes_shaded")
+        print(dict(zip(names, list(ss))), flush=True)
