@@ -195,6 +195,13 @@ int rt_write_ppm(const char *path, const uint8_t *rgb, int32_t rows, int32_t col
 int64_t rt_format_ppm(const uint8_t *rgb, int32_t rows, int32_t cols, int32_t gamma_correct,
                       char *out, size_t out_capacity);
 
+/* ImageOutput.resume's temp-file bytes (ImageOutput.fs:131-161): per pixel `<row>,<col>\n` in ASCII (0 is written as NO
+ * digits, ImageOutput.fs:115-129) followed by the three raw colour bytes.  Returns the length, or a negative status. */
+int64_t rt_format_pixel_map(const uint8_t *rgb, int32_t rows, int32_t cols, uint8_t *out, size_t out_capacity);
+/* ImageOutput.readPixelMap (ImageOutput.fs:46-113): fills rgb_out for every pixel the data names and present_out[r*cols+c]=1
+ * (may be NULL); a truncated tail is ignored as in the reference.  Returns the pixel count, or a negative status. */
+int64_t rt_parse_pixel_map(const uint8_t *data, size_t n, int32_t rows, int32_t cols, uint8_t *rgb_out, uint8_t *present_out);
+
 /* ---- Runtime ------------------------------------------------------------------------------------- */
 int rt_device_count(void);         /* 0 when no HIP device is visible (never an error) */
 const char *rt_last_error(void);   /* thread-local message of the last failing call */

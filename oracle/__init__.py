@@ -43,6 +43,8 @@ for _n, _r, _a in [
                              _i32p, _u8p, _P(A.rt_stats)]),
     ("orc_gamma_correct", C.c_uint8, [C.c_uint8]),
     ("orc_format_ppm", C.c_int64, [_u8p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]),
+    ("orc_format_pixel_map", C.c_int64, [_u8p, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]),
+    ("orc_parse_pixel_map", C.c_int64, [C.c_char_p, C.c_size_t, C.c_int32, C.c_int32, _u8p, _u8p]),
     ("orc_float_producer", C.c_int, [_u32p, C.c_int32, _dp]),
     ("orc_stream_state", C.c_int, [C.c_uint64, C.c_int32, _u64p, _u32p, _u32p]),
     ("orc_bbox_hits", C.c_int, [C.c_int32, _dp, _dp, _i32p]),
@@ -240,6 +242,20 @@ def format_ppm(pixels, gamma=False) -> bytes:
     buf = C.create_string_buffer(int(n) + 1)
     lib.orc_format_ppm(_u8(px), px.shape[0], px.shape[1], int(gamma), buf, int(n) + 1)
     return buf.raw[: int(n)]
+
+
+def format_pixel_map(pixels) -> bytes:
+    px = _c(pixels, np.uint8)
+    n = lib.orc_format_pixel_map(_u8(px), px.shape[0], px.shape[1], None, 0)
+    buf = C.create_string_buffer(int(n))
+    lib.orc_format_pixel_map(_u8(px), px.shape[0], px.shape[1], buf, int(n))
+    return buf.raw[: int(n)]
+
+
+def parse_pixel_map(data: bytes, rows, cols):
+    rgb, present = np.zeros((rows, cols, 3), np.uint8), np.zeros((rows, cols), np.uint8)
+    n = lib.orc_parse_pixel_map(data, len(data), rows, cols, _u8(rgb), _u8(present))
+    return int(n), rgb, present.astype(bool)
 
 
 def plane_map(radius, centre, phi, theta):

@@ -1023,6 +1023,59 @@ static std::string formatPpm(const uint8_t *rgb, int rows, int cols, bool gamma)
     return s;
 }
 
+// ImageOutput.writeAsciiInt (ImageOutput.fs:115-129): emits nothing for 0
+static void writeAsciiInt(std::string &writer, int i) {
+    int places = 0, tmp = i, pw = 1;
+    while (tmp > 0) { tmp = tmp / 10; pw = pw * 10; places = places + 1; }
+    (void) places;
+    pw = pw / 10;
+    while (pw > 0) { writer.push_back((char) ((uint8_t) ((i / pw) % 10) + 48)); pw = pw / 10; }
+}
+// ImageOutput.resume's file body (ImageOutput.fs:144-158)
+static std::string formatPixelMap(const uint8_t *rgb, int rows, int cols) {
+    std::string s;
+    for (int rowNum = 0; rowNum < rows; ++rowNum)
+        for (int colNum = 0; colNum < cols; ++colNum) {
+            const uint8_t *p = rgb + ((size_t) rowNum * (size_t) cols + (size_t) colNum) * 3;
+            writeAsciiInt(s, rowNum);
+            s.push_back((char) 44);
+            writeAsciiInt(s, colNum);
+            s.push_back((char) 10);
+            s.push_back((char) p[0]); s.push_back((char) p[1]); s.push_back((char) p[2]);
+        }
+    return s;
+}
+// ImageOutput.consumeAsciiInteger (ImageOutput.fs:46-66) + readPixelMap's `go` (ImageOutput.fs:68-106)
+static bool consumeAsciiInteger(const uint8_t *d, size_t n, size_t &pos, int &out) {
+    int answer = 0;
+    for (;;) {
+        int i = pos < n ? (int) d[pos++] : -1;
+        if (i < 0) return false;
+        if (48 <= i && i <= 57) answer = (10 * answer + (i - 48));
+        else { out = answer; return true; }
+    }
+}
+static long parsePixelMap(const uint8_t *d, size_t n, int rows, int cols, uint8_t *rgb, uint8_t *present) {
+    size_t pos = 0;
+    long count = 0;
+    for (;;) {
+        int row, col;
+        if (!consumeAsciiInteger(d, n, pos, row)) return count;
+        if (!consumeAsciiInteger(d, n, pos, col)) return count;
+        int r = pos < n ? (int) d[pos++] : -1;
+        if (r < 0) return count;
+        int g = pos < n ? (int) d[pos++] : -1;
+        if (g == -1) return count;
+        int b = pos < n ? (int) d[pos++] : -1;
+        if (b == -1) return count;
+        if (row >= rows || col >= cols) return -1; // dict.[row].[col] would throw
+        size_t o = (size_t) row * (size_t) cols + (size_t) col;
+        rgb[o * 3] = (uint8_t) r; rgb[o * 3 + 1] = (uint8_t) g; rgb[o * 3 + 2] = (uint8_t) b;
+        if (present) present[o] = 1;
+        ++count;
+    }
+}
+
 // ---- conversions from the ABI structs ----------------------------------------------------------
 static Point P3(const double *p) { return Point{p[0], p[1], p[2]}; }
 static Vector V3(const double *p) { return Vector{p[0], p[1], p[2]}; }
@@ -1220,6 +1273,16 @@ int64_t orc_format_ppm(const uint8_t *rgb, int32_t rows, int32_t cols, int32_t g
     std::string s = formatPpm(rgb, rows, cols, gamma != 0);
     if (out && cap > s.size()) { std::memcpy(out, s.data(), s.size()); out[s.size()] = 0; }
     return (int64_t) s.size();
+}
+
+int64_t orc_format_pixel_map(const uint8_t *rgb, int32_t rows, int32_t cols, uint8_t *out, size_t cap) {
+    std::string s = formatPixelMap(rgb, rows, cols);
+    if (out && cap >= s.size()) std::memcpy(out, s.data(), s.size());
+    return (int64_t) s.size();
+}
+int64_t orc_parse_pixel_map(const uint8_t *data, size_t n, int32_t rows, int32_t cols, uint8_t *rgb, uint8_t *present) {
+    if (present) std::memset(present, 0, (size_t) rows * (size_t) cols);
+    return parsePixelMap(data, n, rows, cols, rgb, present);
 }
 
 // ---- per-function hooks (mirror the rt_dev_* hooks of include/rtfs_amd.h) --------------------------

@@ -73,6 +73,8 @@ SIGNATURES = {
     "rt_gamma_correct": (C.c_uint8, [C.c_uint8]),
     "rt_write_ppm": (C.c_int, [C.c_char_p, _u8p, C.c_int32, C.c_int32, C.c_int32]),
     "rt_format_ppm": (C.c_int64, [_u8p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]),
+    "rt_format_pixel_map": (C.c_int64, [_u8p, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]),
+    "rt_parse_pixel_map": (C.c_int64, [C.c_char_p, C.c_size_t, C.c_int32, C.c_int32, _u8p, _u8p]),
     "rt_dev_float_producer": (C.c_int, [C.c_int32, _u32p, C.c_int32, _dp]),
     "rt_dev_stream_state": (C.c_int, [C.c_int32, C.c_uint64, C.c_int32, _u64p, _u32p, _u32p]),
     "rt_dev_bbox_hits": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _i32p]),

@@ -314,4 +314,54 @@ static std::string format_ppm(const uint8_t *rgb, int32_t rows, int32_t cols, bo
     return s;
 }
 
+
+// ---- ImageOutput.resume's temp-file format (ImageOutput.fs:131-161) and readPixelMap (ImageOutput.fs:46-113) ----
+// Per pixel, row-major: writeAsciiInt row ; ',' ; writeAsciiInt col ; '\n' ; R G B as three raw bytes.
+// writeAsciiInt emits NOTHING for 0 (ImageOutput.fs:115-129), which consumeAsciiInteger reads back as 0.
+static inline void append_ascii_int_ref(std::string &s, int v) { // the reference's digit loop, quirk included
+    int tmp = v, pow = 1;
+    while (tmp > 0) { tmp /= 10; pow *= 10; }
+    pow /= 10;
+    while (pow > 0) { s.push_back((char) ('0' + (v / pow) % 10)); pow /= 10; }
+}
+static std::string format_pixel_map(const uint8_t *rgb, int32_t rows, int32_t cols) {
+    std::string s;
+    s.reserve((size_t) rows * (size_t) cols * 12u);
+    for (int32_t r = 0; r < rows; ++r)
+        for (int32_t c = 0; c < cols; ++c) {
+            const uint8_t *p = rgb + ((size_t) r * (size_t) cols + (size_t) c) * 3u;
+            append_ascii_int_ref(s, r); s.push_back(',');
+            append_ascii_int_ref(s, c); s.push_back('\n');
+            s.push_back((char) p[0]); s.push_back((char) p[1]); s.push_back((char) p[2]);
+        }
+    return s;
+}
+// Returns the number of pixels set, or -1 when a (row, col) lies outside the image (the reference would throw).
+// A truncated tail is ignored exactly as the reference's `go` does (ImageOutput.fs:69-106).
+static int64_t parse_pixel_map(const uint8_t *data, size_t n, int32_t rows, int32_t cols, uint8_t *rgb, uint8_t *present) {
+    size_t pos = 0;
+    auto consume = [&](int &out) -> bool { // consumeAsciiInteger: digits, then ONE terminating non-digit; EOF -> ValueNone
+        int answer = 0;
+        while (pos < n) {
+            const int ch = data[pos++];
+            if (48 <= ch && ch <= 57) answer = 10 * answer + (ch - 48);
+            else { out = answer; return true; }
+        }
+        return false;
+    };
+    int64_t count = 0;
+    for (;;) {
+        int row, col;
+        if (!consume(row) || !consume(col)) break;
+        if (pos + 3 > n) break;
+        if (row < 0 || row >= rows || col < 0 || col >= cols) return -1;
+        const size_t o = (size_t) row * (size_t) cols + (size_t) col;
+        rgb[o * 3] = data[pos]; rgb[o * 3 + 1] = data[pos + 1]; rgb[o * 3 + 2] = data[pos + 2];
+        pos += 3;
+        if (present) present[o] = 1;
+        ++count;
+    }
+    return count;
+}
+
 } // namespace rth

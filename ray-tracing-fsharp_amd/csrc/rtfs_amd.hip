@@ -377,6 +377,21 @@ int64_t rt_format_ppm(const uint8_t *rgb, int32_t rows, int32_t cols, int32_t ga
     return (int64_t) s.size();
 }
 
+int64_t rt_format_pixel_map(const uint8_t *rgb, int32_t rows, int32_t cols, uint8_t *out, size_t out_capacity) {
+    if (!rgb || rows <= 0 || cols <= 0) { fail(RT_ERR_INVALID_ARGUMENT, "bad image"); return -RT_ERR_INVALID_ARGUMENT; }
+    std::string s = rth::format_pixel_map(rgb, rows, cols);
+    if (out && out_capacity >= s.size()) memcpy(out, s.data(), s.size());
+    return (int64_t) s.size();
+}
+
+int64_t rt_parse_pixel_map(const uint8_t *data, size_t n, int32_t rows, int32_t cols, uint8_t *rgb_out, uint8_t *present_out) {
+    if ((!data && n) || rows <= 0 || cols <= 0 || !rgb_out) { fail(RT_ERR_INVALID_ARGUMENT, "bad argument"); return -RT_ERR_INVALID_ARGUMENT; }
+    if (present_out) memset(present_out, 0, (size_t) rows * (size_t) cols);
+    const int64_t c = rth::parse_pixel_map(data, n, rows, cols, rgb_out, present_out);
+    if (c < 0) { fail(RT_ERR_INVALID_ARGUMENT, "pixel map names a pixel outside the image"); return -RT_ERR_INVALID_ARGUMENT; }
+    return c;
+}
+
 int rt_write_ppm(const char *path, const uint8_t *rgb, int32_t rows, int32_t cols, int32_t gamma_correct) {
     if (!path || !rgb || rows <= 0 || cols <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad image or path");
     std::string s = rth::format_ppm(rgb, rows, cols, gamma_correct != 0);

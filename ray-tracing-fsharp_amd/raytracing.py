@@ -479,6 +479,40 @@ class ImageOutput:
         return buf.raw[: int(n)]
 
     @staticmethod
+    def toPpm(progressIncrement: Callable[[float], None], image: "Image", path: str) -> str:
+        """ImageOutput.toPpm = resume (ImageOutput.fs:131-161, 205): force the image and spill it as `<row>,<col>\\nRGB` records."""
+        px = np.ascontiguousarray(Image.render(image), dtype=np.uint8)
+        n = lib.rt_format_pixel_map(_u8(px), px.shape[0], px.shape[1], None, 0)
+        if n < 0:
+            check(int(-n))
+        buf = C.create_string_buffer(int(n))
+        lib.rt_format_pixel_map(_u8(px), px.shape[0], px.shape[1], buf, int(n))
+        with open(path, "wb") as f:
+            f.write(buf.raw[: int(n)])
+        for _ in range(px.shape[0]):
+            progressIncrement(1.0)
+        return path
+
+    @staticmethod
+    def readPixelMap(path: str, numRows: int, numCols: int):
+        """ImageOutput.readPixelMap (ImageOutput.fs:68-113) -> (pixels [rows, cols, 3] uint8, present [rows, cols] bool)."""
+        data = open(path, "rb").read()
+        rgb = np.zeros((numRows, numCols, 3), np.uint8)
+        present = np.zeros((numRows, numCols), np.uint8)
+        n = lib.rt_parse_pixel_map(data, len(data), numRows, numCols, _u8(rgb), _u8(present))
+        if n < 0:
+            check(int(-n))
+        return rgb, present.astype(bool)
+
+    @staticmethod
+    def assertComplete(pixel_map) -> np.ndarray:
+        """ImageOutput.assertComplete (ImageOutput.fs:199-200): ValueOption.get on every pixel."""
+        rgb, present = pixel_map
+        if not present.all():
+            raise ValueError("ValueOption.get: the pixel map is incomplete")
+        return rgb
+
+    @staticmethod
     def writePpm(gammaCorrect: bool, incrementProgress: Callable[[float], None], pixels: np.ndarray, output: str) -> None:
         """ImageOutput.writePpm (ImageOutput.fs:163-197)."""
         px = np.ascontiguousarray(pixels, dtype=np.uint8)
