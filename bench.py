@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--pixels", type=int, default=800, help="the reference's `pixels` (maxHeightCoord); image is (3*pixels+1)x(2*pixels+1)")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) is the product path; gloo stages the gather through host memory and lets several ranks share one GPU (rehearsal only)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     args = ap.parse_args()
@@ -100,11 +102,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available() or rt.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()  # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     if args.block or args.chunk:
         rt.set_launch_config(args.block, args.chunk)
 
@@ -147,6 +154,8 @@ def main():
     tot = torch.tensor([dt, float(st["rays"]), float(st["aabb_tests"]), float(st["prim_tests"]), float(st["reflections"]),
                         float(st["samples"]), float(st["pixels_early"]), k_ms / max(1, args.steps)], dtype=torch.float64, device=dev)
     if world > 1:
+        if args.backend == "gloo":
+            tot = tot.cpu()
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot.clone()
@@ -170,6 +179,7 @@ def main():
             "metric": "Mray/s (primary+secondary)", "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "backend": args.backend if world > 1 else None,
             "config": {"workload": f"RTIOW final random-spheres scene (SampleImages.randomSpheres recipe, seed {args.seed}), "
                                    f"maxW={w} maxH={h} -> {cols}x{rows} px, {args.spp} spp adaptive, {args.depth} bounces",
                        "spheres_bounded": info["n_bounded"], "unbounded": info["n_unbounded"], "tree_nodes": info["n_nodes"],

@@ -48,8 +48,11 @@ def gather_frame(local_accum, rows: int, cols: int, rank: int, world: int, group
     assert tuple(local_accum.shape) == (n_pad, cols, 4)
     if world == 1:
         return local_accum[:rows]
-    bufs = [torch.empty_like(local_accum) for _ in range(world)] if rank == 0 else None
-    dist.gather(local_accum, bufs, dst=0, group=group)
+    src = local_accum
+    if dist.get_backend(group) == "gloo" and local_accum.is_cuda:
+        src = local_accum.cpu()  # gloo has no device gather: stage through host memory (CPU tests, one-GPU rehearsals)
+    bufs = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
+    dist.gather(src, bufs, dst=0, group=group)
     if rank != 0:
         return None
     frame = torch.empty((rows, cols, 4), dtype=local_accum.dtype, device=local_accum.device)

@@ -71,3 +71,24 @@ def earth_thumb(earthmap_rows_top_first, spp=30, pixels=18):
 def golden(name):
     import os
     return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+
+
+def many_spheres(n=2600, seed=11, spp=12, depth=8, pixels=10):
+    """A scene whose flattened image (about 136 B per sphere) exceeds the 160 KiB LDS budget, so rt_render must take the
+    global-memory variant of the kernel.  Mixed materials, a Lambert floor and a light dome."""
+    rng = np.random.default_rng(seed)
+    aspect = 16.0 / 9.0
+    cam = dataclasses.replace(rt.Camera.makeBasic(spp, 1.0, aspect, P(0.0, 1.5, -6.0), unit(0.0, -0.2, 1.0), V(0.0, 1.0, 0.0)), BounceDepth=depth)
+    objs = []
+    for i in range(n):
+        c = P(float(rng.uniform(-8, 8)), float(rng.uniform(0.1, 3.0)), float(rng.uniform(-2, 14)))
+        r = float(rng.uniform(0.05, 0.3))
+        col = Px(*(int(x) for x in rng.integers(30, 256, 3)))
+        k = i % 5
+        st = (S.LambertReflection(float(rng.uniform(0.3, 1.0)), Tex(col)) if k < 2 else
+              S.FuzzedReflection(float(rng.uniform(0.5, 1.0)), Tex(col), float(rng.uniform(0.0, 0.5))) if k == 2 else
+              S.Glass(1.0, Tex(rt.Colour.White), 1.5) if k == 3 else S.PureReflection(0.9, Tex(col)))
+        objs.append(H.Sphere(rt.Sphere.make(st, c, r)))
+    objs.append(H.UnboundedSphere(rt.Sphere.make(S.LambertReflection(0.5, Tex(Px(200, 200, 200))), P(0.0, -1000.0, 0.0), 1000.0)))
+    objs.append(H.UnboundedSphere(rt.Sphere.make(S.LightSource(Tex(Px(220, 220, 255))), P(0.0, 0.0, 0.0), 3000.0)))
+    return objs, cam, int(aspect * float(pixels)), pixels

@@ -346,3 +346,14 @@ def test_full_size_config3_properties(rt):
     assert np.all(a.accum[0, :, 0] == 11) and np.all(a.accum[0, :, 1:] == np.array([200, 200, 255]) * 11)
     assert a.stats["rays"] == a.stats["reflections"]  # the scene is closed: every ray hits something
     assert (a.stats["rays"], a.stats["aabb_tests"], a.stats["prim_tests"], a.stats["samples"]) == (3503018818, 98205213022, 11481871042, 1079590420)
+
+
+def test_scene_larger_than_lds_uses_the_global_memory_kernel(rt, orc):
+    """2600 spheres flatten to ~350 KB > 160 KiB of LDS: the LDS=false variant of the render kernel, same bit-exact bar."""
+    objs, cam, w, h = scenes.many_spheres()
+    s = rt.Scene.make(objs)
+    info = s.info()
+    assert info["lds_resident"] == 0 and info["scene_bytes"] > 163840 and info["n_nodes"] == 2 * 2600 - 1
+    res = s.render_rows(w, h, cam, seed=31, counters=True)
+    acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=31, threads=8)
+    _assert_render_equal(res, acc, rgb, st)

@@ -156,3 +156,9 @@ def test_camera_with_syntax(rt):
     c2 = dataclasses.replace(cam, BounceDepth=50, SamplesPerPixel=7)
     abi = c2.to_abi()
     assert (abi.bounce_depth, abi.samples_per_pixel) == (50, 7) and cam.to_abi().bounce_depth == 150
+
+
+def test_lds_residency_is_reported(rt):
+    assert rt.Scene.make(rt.sample_images.config3_final()[0]).info()["lds_resident"] == 1
+    big = rt.Scene.make(scenes.many_spheres(n=2600)[0]).info()
+    assert big["lds_resident"] == 0 and big["scene_bytes"] > 163840
