@@ -92,3 +92,39 @@ def many_spheres(n=2600, seed=11, spp=12, depth=8, pixels=10):
     objs.append(H.UnboundedSphere(rt.Sphere.make(S.LambertReflection(0.5, Tex(Px(200, 200, 200))), P(0.0, -1000.0, 0.0), 1000.0)))
     objs.append(H.UnboundedSphere(rt.Sphere.make(S.LightSource(Tex(Px(220, 220, 255))), P(0.0, 0.0, 0.0), 3000.0)))
     return objs, cam, int(aspect * float(pixels)), pixels
+
+
+def random_scene(seed, pixels=6):
+    """A small random scene for fuzzing: every style can appear, bounded or unbounded, radii of both signs, planes in any
+    orientation, camera anywhere (possibly inside objects), textures now and then."""
+    rng = np.random.default_rng(seed)
+    u = lambda a, b: float(rng.uniform(a, b))  # noqa: E731
+    col = lambda: Px(*(int(x) for x in rng.integers(0, 256, 3)))  # noqa: E731
+    chk = rt.ParameterisedTexture.Checkered(rt.ParameterisedTexture.UvRamp("u", int(rng.integers(0, 256)), "v"),
+                                            rt.ParameterisedTexture.Colour(col()), u(5.0, 60.0))
+
+    def tex(c, r):
+        if rng.random() < 0.15:
+            return rt.ParameterisedTexture.toTexture((abs(r), c), chk)
+        return Tex(col())
+
+    objs = []
+    for _ in range(int(rng.integers(1, 9))):
+        c = P(u(-2, 2), u(-1, 2), u(0, 5))
+        r = u(0.1, 1.2) * (-1.0 if rng.random() < 0.15 else 1.0)
+        k = int(rng.integers(0, 7))
+        st = [S.LightSource(tex(c, r)), S.LightSourceCap(col()), S.PureReflection(u(0, 1), tex(c, r)), S.FuzzedReflection(u(0, 1), tex(c, r), u(0, 1)),
+              S.LambertReflection(u(0, 1), tex(c, r)), S.Dielectric(u(0, 1), tex(c, r), u(0.7, 2.0), u(0, 1)), S.Glass(u(0.5, 1), tex(c, r), u(0.7, 2.0))][k]
+        objs.append((H.UnboundedSphere if rng.random() < 0.3 else H.Sphere)(rt.Sphere.make(st, c, r)))
+    for _ in range(int(rng.integers(0, 3))):
+        n = rng.normal(size=3)
+        k = int(rng.integers(0, 4))
+        st = [PS.LightSource(Tex(col())), PS.PureReflection(u(0, 1), col()), PS.LambertReflection(u(0, 1), col()), PS.FuzzedReflection(u(0, 1), col(), u(0, 1))][k]
+        objs.append(H.InfinitePlane(rt.InfinitePlane.make(st, P(u(-3, 3), u(-3, 3), u(-3, 6)), unit(*n))))
+    if rng.random() < 0.7:
+        objs.append(H.UnboundedSphere(rt.Sphere.make(S.LightSource(Tex(col())), P(0.0, 0.0, 0.0), u(20.0, 300.0))))
+    rng.shuffle(objs)
+    d = rng.normal(size=3)
+    cam = dataclasses.replace(rt.Camera.makeBasic(int(rng.integers(1, 30)), u(0.5, 3.0), u(0.8, 2.0), P(u(-1, 1), u(-0.5, 1.5), u(-3, 1)), unit(*d), V(0.0, 1.0, 0.05)),
+                              BounceDepth=int(rng.integers(0, 25)))
+    return list(objs), cam, int(rng.integers(2, pixels + 1)), int(rng.integers(2, pixels + 1))

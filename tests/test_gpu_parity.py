@@ -357,3 +357,16 @@ def test_scene_larger_than_lds_uses_the_global_memory_kernel(rt, orc):
     res = s.render_rows(w, h, cam, seed=31, counters=True)
     acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=31, threads=8)
     _assert_render_equal(res, acc, rgb, st)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scenes_fuzz(rt, orc, seed):
+    """Random small scenes (every style, both radius signs, planes, cameras inside objects, bounce depths from 0): exact, except
+    that a scene with a parameterised texture may differ in a pixel or two (libm vs OCML ulps)."""
+    objs, cam, w, h = scenes.random_scene(1000 + seed)
+    res, acc, rgb, st = _render_both(rt, orc, objs, cam, w, h, seed=seed)
+    textured = any(o.sphere is not None and o.sphere.Style.texture is not None and o.sphere.Style.texture.param is not None for o in objs)
+    if textured:
+        assert np.count_nonzero(np.any(res.accum != acc, axis=-1)) <= 2
+    else:
+        _assert_render_equal(res, acc, rgb, st)
