@@ -40,7 +40,16 @@ def profiled_traffic():
     vals = dict(line.strip().split(",") for line in open(files[-1]) if "," in line)
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None, None
-    return int((2.0 * float(vals["FETCH_SIZE"]) + float(vals["WRITE_SIZE"])) * 1024), os.path.relpath(files[-1], ROOT)
+    phys = None
+    try:  # the physical reading of the same profile: what actually limits the kernel
+        v = {k: float(x) for k, x in vals.items()}
+        waves_per_simd = v["SQ_WAVES"] / (256 * 4)
+        phys = {"valu_issue_busy_frac": round(v["SQ_ACTIVE_INST_VALU"] * waves_per_simd / v["SQ_WAVE_CYCLES"], 3),
+                "valu_lane_utilisation": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_INSTS_VALU"] * 64.0), 3),
+                "valu_wave_instructions": int(v["SQ_INSTS_VALU"]), "lds_wave_instructions": int(v["SQ_INSTS_LDS"])}
+    except (KeyError, ZeroDivisionError):
+        pass
+    return int((2.0 * float(vals["FETCH_SIZE"]) + float(vals["WRITE_SIZE"])) * 1024), (os.path.relpath(files[-1], ROOT), phys)
 
 
 def cpu_baseline(objs, cam, w, h, seed, target_seconds):
@@ -174,7 +183,8 @@ def main():
         rank_bytes = algorithmic_bytes(st)
         achieved = rank_bytes / (kernel_ms * 1e-3) / 1e9
         info = scene.info()
-        traffic, traffic_src = profiled_traffic() if world == 1 else (None, None)
+        traffic, src = profiled_traffic() if world == 1 else (None, None)
+        traffic_src, physical = src if src else (None, None)
         out = {
             "metric": "Mray/s (primary+secondary)", "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
@@ -190,7 +200,7 @@ def main():
                     "samples_per_s": round(job["samples"] / (ms_per_step * 1e-3), 1),
                     "early_exit_fraction": round(job["pixels_early"] / (rows * cols), 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src, "physical_from_same_profile": physical,
                          "kernel": "rtd::render_kernel", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": rank_bytes,
                          "note": "algorithmic scene bytes (served from LDS); physical HBM traffic is in profiles/ and DESIGN.md"},
         }

@@ -167,6 +167,8 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
         (o.kind == RT_HITTABLE_SPHERE ? bounded : unbounded).push_back((int32_t) i);
     }
     const size_t nb = bounded.size(), nu = unbounded.size(), nobj = nb + nu;
+    // walk offsets are int32 byte offsets with bit 30 reserved for the pending-leaf flag (RTD_LEAF)
+    if (nb > 9000000u || nobj > 16000000u) { status = RT_ERR_UNSUPPORTED; return "scene too large for 32-bit walk offsets (9,000,000 bounded spheres)"; }
     s.objToOrig.clear();
     s.objToOrig.insert(s.objToOrig.end(), bounded.begin(), bounded.end());
     s.objToOrig.insert(s.objToOrig.end(), unbounded.begin(), unbounded.end());

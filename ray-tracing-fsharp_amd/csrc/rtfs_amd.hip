@@ -302,11 +302,15 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     const uint64_t needBlocks = (units + wavesPerBlock - 1) / wavesPerBlock;
     if (grid > needBlocks) grid = needBlocks;
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct Events { // destroyed on every exit path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void) hipEventDestroy(a); if (b) (void) hipEventDestroy(b); }
+    } ev;
     if (stats) {
-        HIP_TRY(hipEventCreate(&ev0));
-        HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipEventCreate(&ev.a));
+        HIP_TRY(hipEventCreate(&ev.b));
     }
+    hipEvent_t &ev0 = ev.a, &ev1 = ev.b;
     HIP_TRY(hipMemsetAsync(scr, 0, RT_SCRATCH_BYTES, st));
     if (grid > 0) {
         if (stats) HIP_TRY(hipEventRecord(ev0, st));
@@ -321,8 +325,6 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
         for (int i = 0; i < 6; ++i) g_last_stage_stats[i] = c[8 + i];
         float ms = 0.f;
         if (grid > 0) HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-        (void) hipEventDestroy(ev0);
-        (void) hipEventDestroy(ev1);
         memset(stats, 0, sizeof(*stats));
         stats->rays = c[0]; stats->aabb_tests = c[1]; stats->prim_tests = c[2]; stats->reflections = c[3];
         stats->samples = c[4]; stats->pixels_early = c[5];
