@@ -133,3 +133,52 @@ def sim_greedy(wn=1.0, wl=1.0, ws=1.0, wr=1.0, batch_nodes=1):
 print("greedy equal weights", ideal / sim_greedy())
 for wn, wl, ws, wr in ((1, 1, 1, 1), (1.5, 1, 1, 1), (2, 1, 1, 1), (1, 2, 1, 1), (1, 1, 1.5, 1), (1, 1, 1, 0.5), (1.5, 1.5, 1, 0.7), (2, 2, 1, 0.7), (3, 3, 1, 1), (2, 3, 1, 0.5)):
     print((wn, wl, ws, wr), round(ideal / sim_greedy(wn, wl, ws, wr), 3))
+
+def sim_two_thresholds(L, Y, RMIN):
+    """node loop exits when pending >= L or done >= Y or nobody is walking; leaf stage if any pending (>= L or stalled);
+    shade when done >= Y or nobody walking."""
+    cost = 0; rays = 0; nxt = 0
+    lanes = [None] * 64
+    def mk():
+        r = new_ray(); r.append(0); return r
+    while True:
+        idle = [i for i in range(64) if lanes[i] is None]
+        busy = 64 - len(idle)
+        if idle and nxt < ITEMS and (len(idle) >= RMIN or busy == 0):
+            for i in idle:
+                if nxt < ITEMS: lanes[i] = mk(); nxt += 1
+            cost += C_REFILL
+        if all(l is None for l in lanes): break
+        while True:
+            trav = [i for i in range(64) if lanes[i] is not None and lanes[i][3] == 0]
+            npend = sum(1 for l in lanes if l is not None and l[3] == 1)
+            ndone = sum(1 for l in lanes if l is not None and l[3] == 2)
+            if not trav or npend >= L or ndone >= Y: break
+            cost += C_NODE
+            for i in trav:
+                r = lanes[i]; p = r[2]; r[2] += 1
+                if p in r[1]: r[3] = 1
+                elif r[2] >= r[0]: r[3] = 2
+        pend = [i for i in range(64) if lanes[i] is not None and lanes[i][3] == 1]
+        trav = [i for i in range(64) if lanes[i] is not None and lanes[i][3] == 0]
+        done = [i for i in range(64) if lanes[i] is not None and lanes[i][3] == 2]
+        if pend and (len(pend) >= L or not trav or len(done) >= Y):
+            cost += C_LEAF
+            for i in pend:
+                r = lanes[i]; r[3] = 0 if r[2] < r[0] else 2
+        done = [i for i in range(64) if lanes[i] is not None and lanes[i][3] == 2]
+        trav = [i for i in range(64) if lanes[i] is not None and lanes[i][3] == 0]
+        pend = [i for i in range(64) if lanes[i] is not None and lanes[i][3] == 1]
+        if done and (len(done) >= Y or (not trav and not pend)):
+            cost += C_SHADE; rays += len(done)
+            for i in done:
+                lanes[i] = None if rng.random() < P_END else mk()
+    return cost / rays
+
+print("--- calibrated costs: node 30, leaf 70, shade 700, refill 250 ---")
+C_NODE, C_LEAF, C_SHADE, C_REFILL = 30, 70, 700, 250
+ideal = (26 * C_NODE + 1.3 * C_LEAF + C_SHADE + C_REFILL * P_END) / 64
+print("one threshold W=44 R=12:", round(ideal / sim_threshold(44, 12), 3))
+for L in (8, 16, 24, 32):
+    for Y in (24, 32, 40, 48):
+        print(f"L={L} Y={Y}", round(ideal / sim_two_thresholds(L, Y, 12), 3))
