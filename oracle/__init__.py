@@ -41,6 +41,7 @@ for _n, _r, _a in [
     ("orc_scene_get_tree", C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _dp]),
     ("orc_render", C.c_int, [C.c_void_p, _P(A.rt_camera), C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                              _i32p, _u8p, _P(A.rt_stats)]),
+    ("orc_set_brute_force", None, [C.c_int]),
     ("orc_gamma_correct", C.c_uint8, [C.c_uint8]),
     ("orc_format_ppm", C.c_int64, [_u8p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]),
     ("orc_format_pixel_map", C.c_int64, [_u8p, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]),
@@ -230,6 +231,11 @@ def arith(op, a, b=None):
     out = np.zeros_like(a)
     _check(lib.orc_arith(op, len(a), _f64(a), _f64(bb) if bb is not None else None, _f64(out)))
     return out
+
+
+def set_brute_force(on: bool) -> None:
+    """Cross-check mode: hitObject tests every bounded sphere without any box (not the reference's algorithm)."""
+    lib.orc_set_brute_force(int(bool(on)))
 
 
 def gamma_correct(b):

@@ -880,10 +880,30 @@ static Best bestCandidate(Inv3 inv, const Ray &ray, Best best, const BoundingBox
     return best;
 }
 
+// Independent cross-check of the tree walk (SURVEY.md 8c pin iv), NOT the reference's algorithm: test every bounded sphere,
+// no boxes.  Equal to the tree walk except for rays that graze a sphere within the 1e-8 discriminant band outside its box.
+static bool g_bruteForce = false;
+static void collectLeaves(const BoundingBoxTree &t, std::vector<const Hittable *> &out) {
+    if (t.leaf) { out.push_back(t.hittable); return; }
+    collectLeaves(*t.left, out);
+    collectLeaves(*t.right, out);
+}
+
 // Scene.hitObject (Scene.fs:62-91)
 static bool hitObject(const Scene &s, const Ray &ray, const Hittable *&outObj, Point &outStrike, Counters &cnt) {
     cnt.rays++;
     Best best{std::numeric_limits<double>::infinity(), nullptr, std::numeric_limits<double>::quiet_NaN()};
+    if (s.tree && g_bruteForce) {
+        std::vector<const Hittable *> leaves;
+        collectLeaves(*s.tree, leaves); // same visiting order as the walk
+        for (const Hittable *h : leaves) {
+            double point;
+            if (HittableM::hits(ray, *h, point, cnt)) {
+                double a = point * point;
+                if (a < best.bestFloat) best = Best{a, h, point};
+            }
+        }
+    } else
     if (s.tree) best = bestCandidate(BBox::inverseDirections(ray), ray, best, *s.tree, cnt);
     for (const Hittable *i : s.unbounded) {
         double point;
@@ -1266,6 +1286,8 @@ int orc_render(const orc_scene *sc, const rt_camera *cam, int32_t max_w, int32_t
     }
     return RT_OK;
 }
+
+void orc_set_brute_force(int on) { SceneM::g_bruteForce = on != 0; }
 
 uint8_t orc_gamma_correct(uint8_t b) { return gammaCorrect(b); }
 

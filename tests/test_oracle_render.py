@@ -102,3 +102,27 @@ def test_monte_carlo_agrees_with_an_independent_estimate(rt, orc):
     acc, rgb, st = orc.OracleScene(objs).render_rows(2, 2, cam.to_abi(), seed=4)
     mean = acc[..., 1] / acc[..., 0]
     assert np.all(np.abs(mean - 100.0) <= 1.0)  # darken 0.5 of 255 = 128; combine(128, 200) = 100
+
+
+def test_tree_walk_agrees_with_brute_force(rt, orc):
+    """SURVEY.md 8c pin (iv): the unpruned tree walk finds the same closest hit as testing every sphere.  They may differ only
+    for rays grazing a sphere inside Sphere.firstIntersection's 1e-8 discriminant band but outside its box, so: identical
+    closest objects on 100k random rays up to a handful, and near-identical renders."""
+    objs, cam, w, h = scenes.small_final(spp=24, pixels=12)
+    o = orc.OracleScene(objs)
+    rays = scenes.random_rays(100000, 5, origin_scale=5.0)
+    rays[:50000, :3] = [13.0, 2.0, -3.0]
+    hit_tree, strike_tree, cnt_tree = o.hit_object(rays)
+    acc_tree, _, st_tree = o.render_rows(w, h, cam.to_abi(), seed=3, threads=4)
+    try:
+        orc.set_brute_force(True)
+        hit_bf, strike_bf, cnt_bf = o.hit_object(rays)
+        acc_bf, _, st_bf = o.render_rows(w, h, cam.to_abi(), seed=3, threads=4)
+    finally:
+        orc.set_brute_force(False)
+    assert np.count_nonzero(hit_tree != hit_bf) <= 3
+    same = hit_tree == hit_bf
+    assert np.array_equal(strike_tree[same & (hit_tree >= 0)], strike_bf[same & (hit_bf >= 0)])
+    assert cnt_bf[:, 0].sum() == 0 and cnt_bf[:, 1].min() >= 485  # no boxes; every sphere tested
+    assert np.mean(np.any(acc_tree != acc_bf, axis=-1)) < 0.01
+    assert abs(int(st_tree["rays"]) - int(st_bf["rays"])) < 0.01 * st_tree["rays"]
