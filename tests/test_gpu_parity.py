@@ -370,3 +370,24 @@ def test_random_scenes_fuzz(rt, orc, seed):
         assert np.count_nonzero(np.any(res.accum != acc, axis=-1)) <= 2
     else:
         _assert_render_equal(res, acc, rgb, st)
+
+
+def test_edge_shards_and_extremes(rt, orc):
+    """Empty shards (more ranks than rows), a one-row image, one-pixel-wide units, spp far above the pixel count, depth 0."""
+    objs, cam, w, h = scenes.all_materials(pixels=3)
+    s, o = rt.Scene.make(objs), orc.OracleScene(objs)
+    rows = 2 * h + 1
+    empty = s.render_rows(w, h, cam, seed=1, row_first=rows + 5, row_stride=rows + 9, n_rows=0)
+    assert empty.accum.shape[0] == 0 and empty.stats["samples"] == 0
+    one = s.render_rows(w, h, cam, seed=1, row_first=rows - 1, row_stride=1, n_rows=1, counters=True)
+    acc, rgb, st = o.render_rows(w, h, cam.to_abi(), seed=1, row_first=rows - 1, row_stride=1, n_rows=1)
+    _assert_render_equal(one, acc, rgb, st)
+    big = dataclasses.replace(cam, SamplesPerPixel=3000, BounceDepth=0)
+    try:
+        rt.set_launch_config(256, 1)
+        res = s.render_rows(1, 1, big, seed=2, counters=True)
+    finally:
+        rt.set_launch_config(0, 0)
+    acc, rgb, st = o.render_rows(1, 1, big.to_abi(), seed=2, threads=4)
+    _assert_render_equal(res, acc, rgb, st)
+    assert set(np.unique(res.accum[..., 0])) <= {11, 3000}
