@@ -1241,7 +1241,8 @@ int orc_render(const orc_scene *sc, const rt_camera *cam, int32_t max_w, int32_t
     std::vector<Counters> cnts((size_t) n_threads);
     std::vector<uint64_t> earlies((size_t) n_threads, 0);
     auto worker = [&](int tid) {
-        Counters &cnt = cnts[(size_t) tid];
+        Counters cnt; // thread-local while rendering (adjacent per-thread slots would false-share their cache lines)
+        uint64_t earlyLocal = 0;
         for (;;) {
             int64_t u = next.fetch_add(1);
             if (u >= nUnits) break;
@@ -1259,9 +1260,11 @@ int orc_render(const orc_scene *sc, const rt_camera *cam, int32_t max_w, int32_t
                 size_t o = (size_t) lp;
                 if (accum) { accum[o * 4 + 0] = st.Count; accum[o * 4 + 1] = st.SumRed; accum[o * 4 + 2] = st.SumGreen; accum[o * 4 + 3] = st.SumBlue; }
                 if (rgb) { rgb[o * 3 + 0] = p.Red; rgb[o * 3 + 1] = p.Green; rgb[o * 3 + 2] = p.Blue; }
-                if (early) earlies[(size_t) tid]++;
+                if (early) earlyLocal++;
             }
         }
+        cnts[(size_t) tid] = cnt;
+        earlies[(size_t) tid] = earlyLocal;
     };
     if (n_threads == 1) worker(0);
     else {

@@ -391,3 +391,18 @@ def test_edge_shards_and_extremes(rt, orc):
     acc, rgb, st = o.render_rows(1, 1, big.to_abi(), seed=2, threads=4)
     _assert_render_equal(res, acc, rgb, st)
     assert set(np.unique(res.accum[..., 0])) <= {11, 3000}
+
+
+def test_config5_full_geometry_row(rt, orc):
+    """BASELINE config 5 at full geometry (2401x1601, 2000 spp): one image row through the textured sphere and the mirror plane.
+    The earth texture goes through acos/atan2, so a few pixels may differ by a flipped texel."""
+    earth = scenes.golden("earthmap_rgb")["rgb"]
+    objs, cam, w, h = rt.sample_images.config5_mixed(earth)
+    assert cam.SamplesPerPixel == 2000 and (w, h) == (1200, 800)
+    s, o = rt.Scene.make(objs), orc.OracleScene(objs)
+    assert s.info()["texel_bytes"] >= 1024 * 512 * 3
+    res = s.render_rows(w, h, cam, seed=5, row_first=700, row_stride=1, n_rows=1, counters=True)
+    acc, rgb, st = o.render_rows(w, h, cam.to_abi(), seed=5, row_first=700, row_stride=1, n_rows=1, threads=8)
+    differing = np.count_nonzero(np.any(res.accum != acc, axis=-1))
+    assert differing <= 4, differing
+    assert set(np.unique(res.accum[..., 0])) <= {11, 2000}
