@@ -52,6 +52,26 @@ def profiled_traffic():
     return int((2.0 * float(vals["FETCH_SIZE"]) + float(vals["WRITE_SIZE"])) * 1024), (os.path.relpath(files[-1], ROOT), phys)
 
 
+def effective_cpus() -> int:
+    """Host cores this process may actually use: the cgroup CPU quota when there is one (the GPU box shows 256 hardware
+    threads but grants 16 CPUs; oversubscribing the quota throttles and makes the baseline look 1.5x slower), else the
+    scheduler affinity."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(objs, cam, w, h, seed, target_seconds):
     """The oracle (kind "port": a C++ restatement; the F#/.NET reference cannot run in this image) on all host cores, on a
     bounded sample of the SAME workload: every `stride`-th image row of the frame, sized by a short calibration pass so the
@@ -59,7 +79,7 @@ def cpu_baseline(objs, cam, w, h, seed, target_seconds):
     import oracle as orc
 
     rows = 2 * h + 1
-    threads = max(1, orc.hardware_threads())
+    threads = effective_cpus()
     scene = orc.OracleScene(objs)
 
     def run(stride):
@@ -76,7 +96,7 @@ def cpu_baseline(objs, cam, w, h, seed, target_seconds):
     stride = max(1, min(cal_stride, int(round(full_rays / max(rate * target_seconds, 1.0)))))
     if stride < cal_stride:
         st, dt, first, n = run(stride)
-    return {"value": round(st["rays"] / dt / 1e6, 4), "unit": "Mray/s", "cores": threads, "kind": "port",
+    return {"value": round(st["rays"] / dt / 1e6, 4), "unit": "Mray/s", "cores": threads, "hardware_threads": orc.hardware_threads(), "kind": "port",
             "sample": f"{n} of {rows} image rows (every {stride}th from row {first}) of the same frame: {st['rays']} rays in {dt:.1f} s; "
                       f"oracle = C++ restatement of the F# path (the .NET reference cannot run in this image)",
             "rays": st["rays"], "seconds": round(dt, 2)}
