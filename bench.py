@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--pixels", type=int, default=800, help="the reference's `pixels` (maxHeightCoord); image is (3*pixels+1)x(2*pixels+1)")
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"],
+                    help="BASELINE.json config: c3 (default, the metric's config) final scene 2401x1601x500spp; c2 three Lambert spheres "
+                         "801x451x100spp; c4 final scene 7681x4321x1000spp; c5 final scene + earth texture + plane + Dielectric, 2000spp")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) is the product path; gloo stages the gather through host memory and lets several ranks share one GPU (rehearsal only)")
@@ -144,7 +147,21 @@ def main():
     if args.block or args.chunk:
         rt.set_launch_config(args.block, args.chunk)
 
-    objs, cam, w, h = rt.sample_images.config3_final(seed=args.seed, spp=args.spp, depth=args.depth, pixels=args.pixels)
+    if args.workload == "c3":
+        objs, cam, w, h = rt.sample_images.config3_final(seed=args.seed, spp=args.spp, depth=args.depth, pixels=args.pixels)
+        label = "RTIOW final random-spheres scene (SampleImages.randomSpheres recipe"
+    elif args.workload == "c2":
+        objs, cam, w, h = rt.sample_images.config2_three_lambert()
+        label = "config 2: three Lambert spheres + floor + dome (SURVEY.md 8d"
+    elif args.workload == "c4":
+        objs, cam, _, _ = rt.sample_images.config3_final(seed=args.seed, spp=1000, depth=args.depth)
+        w, h = 3840, 2160
+        label = "config 4: final scene at maxW=3840 maxH=2160 (SampleImages.randomSpheres recipe"
+    else:
+        import numpy as np
+        earth = np.load(os.path.join(ROOT, "tests", "golden", "earthmap_rgb.npz"))["rgb"]
+        objs, cam, w, h = rt.sample_images.config5_mixed(earth, seed=args.seed, depth=args.depth)
+        label = "config 5: final scene + earth-textured sphere + Dielectric sphere + mirror InfinitePlane (recipe"
     scene = rt.Scene.make(objs)
     rows, cols = 2 * h + 1, 2 * w + 1
     first, stride, n = rtd.shard_rows(rows, rank, world)
@@ -212,8 +229,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "backend": args.backend if world > 1 else None,
-            "config": {"workload": f"RTIOW final random-spheres scene (SampleImages.randomSpheres recipe, seed {args.seed}), "
-                                   f"maxW={w} maxH={h} -> {cols}x{rows} px, {args.spp} spp adaptive, {args.depth} bounces",
+            "config": {"workload": f"{label}, seed {args.seed}), "
+                                   f"maxW={w} maxH={h} -> {cols}x{rows} px, {cam.SamplesPerPixel} spp adaptive, {cam.BounceDepth} bounces",
                        "spheres_bounded": info["n_bounded"], "unbounded": info["n_unbounded"], "tree_nodes": info["n_nodes"],
                        "lds_resident_scene": bool(info["lds_resident"]), "sharding": f"rows interleaved over {world} rank(s), one gather"},
             "job": {**job, "pixels": rows * cols, "wall_s_per_frame": round(ms_per_step / 1e3, 4),
