@@ -214,9 +214,13 @@ int rt_set_launch_config(int32_t block_threads, int32_t chunk_pixels, int32_t bl
 /* Lane-scheduling thresholds of the render kernel (DESIGN.md "Kernel"): a stage yields once `yield_lanes` lanes wait for
  * another stage; idle lanes are refilled once `refill_lanes` are idle.  0 keeps the default.  Results never depend on them. */
 int rt_set_schedule(int32_t yield_lanes, int32_t refill_lanes);
+/* 1: always the fused kernel; 2: always two passes (phase 1 + decision, cost-ordered phase 2); 0: choose by shard size.
+ * Results never depend on it. */
+int rt_set_passes(int32_t passes);
 /* Diagnostic: wave-level stage executions of this process' last render that had RT_RENDER_COUNTERS set:
- * {refill stages, node-loop trips, leaf stages, shade stages, lanes refilled, lanes shaded}. */
-int rt_last_stage_stats(uint64_t out[6]);
+ * {refill stages, node-loop trips, leaf stages, shade stages, lanes refilled, lanes shaded, sum of wave lifetimes and
+ * first-start-to-last-end span (both in 100 MHz ticks), waves launched}. */
+int rt_last_stage_stats(uint64_t out[9]);
 
 /*
  * ---- Device unit hooks ---------------------------------------------------------------------------

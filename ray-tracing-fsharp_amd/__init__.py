@@ -23,3 +23,9 @@ def set_launch_config(block_threads: int = 0, chunk_pixels: int = 0, blocks_per_
 def set_schedule(yield_lanes: int = 0, refill_lanes: int = 0) -> None:
     from ._lib import check
     check(lib.rt_set_schedule(yield_lanes, refill_lanes))
+
+
+def set_passes(passes: int = 0) -> None:
+    """0 auto, 1 fused kernel, 2 two-pass (phase 1 + decision, then cost-ordered phase 2).  Never changes a result."""
+    from ._lib import check
+    check(lib.rt_set_passes(passes))

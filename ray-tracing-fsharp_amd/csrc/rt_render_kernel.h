@@ -39,14 +39,22 @@ struct RenderParams {
     uint8_t *rgb;                  // [n_rows*cols][3] or null
     unsigned long long *counters;  // [16]: rays, aabb, prim, refl, samples, pixels_early, -, -, then stage executions (COUNT):
                                    //       [8] refill [9] node trips [10] leaf stages [11] shade stages [12] lanes refilled [13] lanes shaded
-    unsigned int *queue;           // work-unit counter, zeroed before launch
+    unsigned int *queue;           // work-unit counter of the fused kernel / of pass A, zeroed before launch
+    // two-pass rendering (see render_kernel): pass A appends (cost << 32 | local pixel) for every pixel that continues;
+    // pass B walks `live_list` (those pixels ordered by decreasing cost) with its own queue
+    unsigned long long *pairs;
+    const unsigned int *live_list;
+    unsigned int *live_count;      // number of pairs / list entries (device side)
+    unsigned long long *queue_b;   // next unassigned list entry
+    uint32_t total_waves;          // waves of the grid (guided unit sizes in pass B)
 };
 
 // Per-wave LDS scratch (in 4-byte words), P = pixels per work unit:
 //   acc  [2][P][3]  sums of slot 0 / slot 1
 //   pix  [P][4]     row, col, pixel stream key lo, hi
 //   live [P]        compacted pixel slots for phase 2
-#define RTD_WAVE_WORDS(P) (11u * (uint32_t) (P))
+//   cost [P]        rays traced for the pixel in phase 1 (pass A only: the cost estimate that orders pass B)
+#define RTD_WAVE_WORDS(P) (12u * (uint32_t) (P))
 
 // Wave-private LDS words: adds from many lanes may land on one word (same pixel), so they are ds_add_u32; the owner
 // lane later takes the sum and clears the word in one ds_wrxchg.  One wave's LDS operations execute in order.
@@ -101,7 +109,7 @@ struct StageStats { uint32_t refill, trips, leaf, shade, refillLanes, shadeLanes
 // each stage until its slowest lane finishes leaves ~70 % of the lanes idle.  Instead a stage runs while enough lanes
 // want it and yields to the stage that has collected the most waiting lanes; a ray with a long walk simply stays in WALK
 // across several rounds.  Which lane computes what when has no effect on any result (streams are per item).
-template <bool LDS, bool COUNT>
+template <bool LDS, bool COUNT, bool COST>
 RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_AS3 uint32_t *acc, const RTD_AS3 uint32_t *pix,
                           const RTD_AS3 uint32_t *live, bool use_live, uint32_t total, uint32_t per, uint32_t s_base,
                           uint32_t split, Counters &cnt, StageStats &ss) {
@@ -129,7 +137,7 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
                 int row = (int) pix[slot * 4 + 0], col = (int) pix[slot * 4 + 1];
                 uint64_t pkey = (uint64_t) pix[slot * 4 + 2] | ((uint64_t) pix[slot * 4 + 3] << 32);
                 rng = stream_for(pkey, s);
-                slotOff = ((s < split) ? 0u : (uint32_t) p.chunk * 3u) + slot * 3u;
+                slotOff = (((s < split) ? 0u : (uint32_t) p.chunk * 3u) + slot * 3u) | (slot << 16); // low half: acc word, high half: pixel slot
                 colour = RTD_WHITE;
                 bounces = 0;
                 if (camera_ray(p.cam, row, col, rng, o, d)) {
@@ -195,11 +203,13 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
                 }
             }
             if (done) {
+                const uint32_t aoff = slotOff & 0xFFFFu;
                 if (result != 0u) { // PixelStats.add (Pixel.fs:97-101); Count is implied by the item count
-                    lds_add(acc + slotOff + 0, result & 0xFFu);
-                    lds_add(acc + slotOff + 1, (result >> 8) & 0xFFu);
-                    lds_add(acc + slotOff + 2, (result >> 16) & 0xFFu);
+                    lds_add(acc + aoff + 0, result & 0xFFu);
+                    lds_add(acc + aoff + 1, (result >> 8) & 0xFFu);
+                    lds_add(acc + aoff + 2, (result >> 16) & 0xFFu);
                 }
+                if (COST) lds_add(acc + 11u * (uint32_t) p.chunk + (slotOff >> 16), (uint32_t) bounces + 1u); // Scene.hitObject calls of this path
                 st = IDLE;
                 w.off = end;
             } else {
@@ -211,7 +221,15 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
     }
 }
 
-template <bool LDS, bool COUNT, int BLOCK>
+// MODE 0: fused -- a unit's pixels go through phase 1, the adaptive decision and phase 2 on one wave.
+// MODE 1: pass A -- phase 1 and the decision for every pixel; pixels that continue are appended to `pairs` with the number of
+//         rays their 2k+1 samples took (a cost estimate), the others are final.
+// MODE 2: pass B -- phase 2 for the pixels of `live_list`, which the host-side launch sequence has ordered by decreasing cost
+//         (longest job first); unit size shrinks with the remaining list, down to one pixel.
+// Per-pixel cost is heavy-tailed (a pixel on a glass sphere: ~20 rays per sample, 4 ms of one wave), so when a shard has only a few
+// units per wave the fused kernel ends with most waves waiting for a few long units started late; A + sort + B removes that tail.
+// Every mode computes the same integers: which wave traces which sample when has no effect (streams are per item).
+template <bool LDS, bool COUNT, int BLOCK, int MODE>
 __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -237,25 +255,45 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     const int n2s = p.cam.spp - 2 * p.k - 1; // Scene.fs:191
     const uint32_t n2 = n2s > 0 ? (uint32_t) n2s : 0u;
 
+    const unsigned long long tStart = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
     Counters cnt; cnt.rays = cnt.aabb = cnt.prim = cnt.refl = 0;
     StageStats ss; ss.refill = ss.trips = ss.leaf = ss.shade = ss.refillLanes = ss.shadeLanes = 0;
     uint32_t earlyCount = 0;
     uint64_t sampleCount = 0; // Scene.traceOnce calls = sum of PixelStats.Count
 
+    const unsigned long long nList = (MODE == 2) ? (unsigned long long) *p.live_count : 0ull;
     for (;;) {
-        uint32_t unit = 0;
-        if (lane == 0) unit = atomicAdd(p.queue, 1u);
-        unit = __builtin_amdgcn_readfirstlane(unit);
-        const uint64_t first = (uint64_t) unit * P;
-        if (first >= nLocal) break;
-        const uint32_t npx = (uint32_t) ((nLocal - first < (uint64_t) P) ? (nLocal - first) : (uint64_t) P);
+        unsigned long long first = 0;
+        uint32_t npx = 0;
+        if (MODE == 2) {
+            if (lane == 0) { // guided self-scheduling over the cost-ordered list: big units first, single pixels at the end
+                const unsigned long long seen = __hip_atomic_load(p.queue_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen < nList) {
+                    unsigned long long want = (nList - seen) / (2ull * p.total_waves);
+                    want = want < 1ull ? 1ull : (want > (unsigned long long) P ? (unsigned long long) P : want);
+                    first = atomicAdd(p.queue_b, want);
+                    if (first < nList) npx = (uint32_t) ((nList - first < want) ? (nList - first) : want);
+                }
+            }
+            npx = __builtin_amdgcn_readfirstlane(npx);
+            first = ((unsigned long long) __builtin_amdgcn_readfirstlane((uint32_t) (first >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t) first);
+        } else {
+            uint32_t unit = 0;
+            if (lane == 0) unit = atomicAdd(p.queue, 1u);
+            unit = __builtin_amdgcn_readfirstlane(unit);
+            first = (unsigned long long) unit * P;
+            if (first < nLocal) npx = (uint32_t) ((nLocal - first < (unsigned long long) P) ? (nLocal - first) : (unsigned long long) P);
+        }
+        if (npx == 0u) break;
 
         // per-pixel coordinates (Scene.fs:219,226) and stream key; clear the accumulators
         for (uint32_t i = (uint32_t) lane; i < 6u * P; i += 64u) acc[i] = 0u;
+        if (MODE == 1 && (uint32_t) lane < P) acc[11u * P + lane] = 0u;
+        unsigned long long lp = 0; // local pixel of lane j < npx
         if ((uint32_t) lane < npx) {
-            uint64_t lp = first + (uint32_t) lane;
-            uint32_t lr = (uint32_t) (lp / (uint64_t) p.cols);
-            uint32_t c = (uint32_t) (lp - (uint64_t) lr * (uint64_t) p.cols);
+            lp = (MODE == 2) ? (unsigned long long) p.live_list[first + (uint32_t) lane] : first + (uint32_t) lane;
+            uint32_t lr = (uint32_t) (lp / (unsigned long long) p.cols);
+            uint32_t c = (uint32_t) (lp - (unsigned long long) lr * (unsigned long long) p.cols);
             uint32_t r = (uint32_t) p.row_first + lr * (uint32_t) p.row_stride;
             uint64_t pkey = pixel_key(p.seed_key, (uint64_t) r * (uint64_t) p.cols + c); // global pixel index
             pix[lane * 4 + 0] = (uint32_t) (p.cam.max_h - (int) r - 1);
@@ -265,51 +303,71 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
         }
         __builtin_amdgcn_wave_barrier();
 
-        // ---- phase 1: 2k+1 samples per pixel, sums split after sample k (Scene.fs:172-182) ----
-        run_items<LDS, COUNT>(p, sc, acc, pix, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- decide (Scene.fs:177-188) and compact the pixels that continue ----
         int sumR = 0, sumG = 0, sumB = 0, count = 0;
         bool cont = false;
-        if ((uint32_t) lane < npx) {
-            int aR = (int) lds_take(acc + lane * 3 + 0), aG = (int) lds_take(acc + lane * 3 + 1), aB = (int) lds_take(acc + lane * 3 + 2);
-            int bR = (int) lds_take(acc + P * 3 + lane * 3 + 0), bG = (int) lds_take(acc + P * 3 + lane * 3 + 1),
-                bB = (int) lds_take(acc + P * 3 + lane * 3 + 2);
-            int c1 = (int) k + 1;
-            count = (int) n1;
-            sumR = aR + bR; sumG = aG + bG; sumB = aB + bB;
-            // PixelStats.mean (Pixel.fs:103-108) is integer division; Pixel.difference (Pixel.fs:113-116) is L1
-            int oR = (aR / c1) & 0xFF, oG = (aG / c1) & 0xFF, oB = (aB / c1) & 0xFF;
-            int nR = (sumR / count) & 0xFF, nG = (sumG / count) & 0xFF, nB = (sumB / count) & 0xFF;
-            int diff = abs(nR - oR) + abs(nG - oG) + abs(nB - oB);
-            if (diff == 0) earlyCount++;
-            cont = (diff != 0) && (n2 > 0u);
+        uint32_t nLive = 0;
+        if (MODE != 2) {
+            // ---- phase 1: 2k+1 samples per pixel, sums split after sample k (Scene.fs:172-182) ----
+            run_items<LDS, COUNT, MODE == 1>(p, sc, acc, pix, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- decide (Scene.fs:177-188) and compact the pixels that continue ----
+            if ((uint32_t) lane < npx) {
+                int aR = (int) lds_take(acc + lane * 3 + 0), aG = (int) lds_take(acc + lane * 3 + 1), aB = (int) lds_take(acc + lane * 3 + 2);
+                int bR = (int) lds_take(acc + P * 3 + lane * 3 + 0), bG = (int) lds_take(acc + P * 3 + lane * 3 + 1),
+                    bB = (int) lds_take(acc + P * 3 + lane * 3 + 2);
+                int c1 = (int) k + 1;
+                count = (int) n1;
+                sumR = aR + bR; sumG = aG + bG; sumB = aB + bB;
+                // PixelStats.mean (Pixel.fs:103-108) is integer division; Pixel.difference (Pixel.fs:113-116) is L1
+                int oR = (aR / c1) & 0xFF, oG = (aG / c1) & 0xFF, oB = (aB / c1) & 0xFF;
+                int nR = (sumR / count) & 0xFF, nG = (sumG / count) & 0xFF, nB = (sumB / count) & 0xFF;
+                int diff = abs(nR - oR) + abs(nG - oG) + abs(nB - oB);
+                if (diff == 0) earlyCount++;
+                cont = (diff != 0) && (n2 > 0u);
+            }
+            const unsigned long long liveMask = __builtin_amdgcn_ballot_w64(cont);
+            nLive = (uint32_t) __popcll(liveMask);
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (liveMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) liveMask, 0u));
+            if (MODE == 0) {
+                if (cont) live[pos] = (uint32_t) lane;
+            } else if (nLive > 0u) { // pass A: hand the pixel over to pass B, with its cost estimate
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(p.live_count, nLive);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (cont) p.pairs[base + pos] = ((unsigned long long) acc[11u * P + lane] << 32) | (unsigned long long) (uint32_t) lp;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        unsigned long long liveMask = __builtin_amdgcn_ballot_w64(cont);
-        uint32_t nLive = (uint32_t) __popcll(liveMask);
-        if (cont) {
-            uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (liveMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) liveMask, 0u));
-            live[pos] = (uint32_t) lane;
-        }
-        __builtin_amdgcn_wave_barrier();
 
         // ---- phase 2: the remaining spp-2k-1 samples of the surviving pixels (Scene.fs:191-192) ----
-        if (nLive > 0u) {
-            run_items<LDS, COUNT>(p, sc, acc, pix, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
+        if (MODE == 0 && nLive > 0u) {
+            run_items<LDS, COUNT, false>(p, sc, acc, pix, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (MODE == 2) {
+            run_items<LDS, COUNT, false>(p, sc, acc, pix, live, false, npx * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
             __builtin_amdgcn_wave_barrier();
         }
 
         // ---- PixelStats and mean out: one 16-byte store per pixel ----
         if ((uint32_t) lane < npx) {
-            if (cont) {
-                sumR += (int) lds_take(acc + lane * 3 + 0);
-                sumG += (int) lds_take(acc + lane * 3 + 1);
-                sumB += (int) lds_take(acc + lane * 3 + 2);
-                count += (int) n2;
+            if (MODE == 2) { // add phase 2 to what pass A left (this wave is the only writer of the pixel)
+                const i4 prev = ((const i4 *) p.accum)[lp];
+                sumR = prev.y + (int) lds_take(acc + lane * 3 + 0);
+                sumG = prev.z + (int) lds_take(acc + lane * 3 + 1);
+                sumB = prev.w + (int) lds_take(acc + lane * 3 + 2);
+                count = prev.x + (int) n2;
+                sampleCount += (uint64_t) n2;
+            } else {
+                if (MODE == 0 && cont) {
+                    sumR += (int) lds_take(acc + lane * 3 + 0);
+                    sumG += (int) lds_take(acc + lane * 3 + 1);
+                    sumB += (int) lds_take(acc + lane * 3 + 2);
+                    count += (int) n2;
+                }
+                sampleCount += (uint64_t) count;
             }
-            uint64_t lp = first + (uint32_t) lane;
-            sampleCount += (uint64_t) count;
             i4 out; out.x = count; out.y = sumR; out.z = sumG; out.w = sumB;
             ((i4 *) p.accum)[lp] = out;
             if (p.rgb) {
@@ -336,11 +394,44 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
             atomicAdd(&p.counters[11], (unsigned long long) ss.shade);
             atomicAdd(&p.counters[12], (unsigned long long) ss.refillLanes);
             atomicAdd(&p.counters[13], (unsigned long long) ss.shadeLanes);
+            const unsigned long long tEnd = __builtin_amdgcn_s_memrealtime();
+            atomicAdd(&p.counters[14], tEnd - tStart);                         // sum of wave lifetimes
+            atomicMax(&p.counters[15], tEnd);                                  // last wave to finish
+            atomicMax(&p.counters[7], 0x4000000000000000ull - tStart);         // (2^62 - earliest start)
         }
     }
     if (lane == 0) {
         atomicAdd(&p.counters[4], (unsigned long long) s);
         atomicAdd(&p.counters[5], (unsigned long long) e);
+    }
+}
+
+
+// ---- ordering of the pass-B list: bucket sort of (cost, pixel) pairs, heaviest first -------------------------------------------
+// 64 buckets over rays per phase-1 sample (x4); order inside a bucket is arbitrary (it only changes which wave traces what).
+#define RTD_COST_BUCKETS 64
+RTD_INLINE uint32_t cost_bucket(unsigned long long pair, uint32_t n1) {
+    const uint32_t cost = (uint32_t) (pair >> 32);
+    const uint32_t b = (cost * 4u) / n1;
+    return b >= RTD_COST_BUCKETS ? RTD_COST_BUCKETS - 1u : b;
+}
+__global__ void sort_hist_kernel(const unsigned long long *pairs, const unsigned int *count, uint32_t n1, unsigned int *hist) {
+    const unsigned int n = *count;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&hist[cost_bucket(pairs[i], n1)], 1u);
+}
+__global__ void sort_offsets_kernel(const unsigned int *hist, unsigned int *offsets) { // descending cost: bucket 63 first
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned int run = 0;
+        for (int b = RTD_COST_BUCKETS - 1; b >= 0; --b) { offsets[b] = run; run += hist[b]; }
+    }
+}
+__global__ void sort_scatter_kernel(const unsigned long long *pairs, const unsigned int *count, uint32_t n1, const unsigned int *offsets,
+                                    unsigned int *cursor, unsigned int *list) {
+    const unsigned int n = *count;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long pr = pairs[i];
+        const uint32_t b = cost_bucket(pr, n1);
+        list[offsets[b] + atomicAdd(&cursor[b], 1u)] = (unsigned int) (pr & 0xFFFFFFFFull);
     }
 }
 

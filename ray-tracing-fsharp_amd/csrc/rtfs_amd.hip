@@ -63,8 +63,9 @@ struct rt_scene {
     std::mutex mu;
 };
 
-static unsigned long long g_last_stage_stats[6] = {0};
+static unsigned long long g_last_stage_stats[9] = {0};
 static int g_block_threads = 0, g_chunk_pixels = 0, g_blocks_per_cu = 0, g_yield_lanes = 0, g_refill_lanes = 0;
+static int g_passes = 0; // 0 auto, 1 fused kernel, 2 two-pass (A, sort, B)
 
 static int device_scene(rt_scene *s, int device, DeviceScene **out) {
     std::lock_guard<std::mutex> lock(s->mu);
@@ -102,21 +103,24 @@ static bool lds_fits(const rth::HostScene &h, int block_threads, int chunk) {
 // launch
 // ------------------------------------------------------------------------------------------------------------
 typedef void (*render_fn)(const RenderParams);
-static render_fn pick_kernel(bool lds, bool count, int block) {
+template <int MODE> static render_fn pick_mode(bool lds, bool count, int block) {
     if (block == 1024) {
-        if (lds) return count ? render_kernel<true, true, 1024> : render_kernel<true, false, 1024>;
-        return count ? render_kernel<false, true, 1024> : render_kernel<false, false, 1024>;
+        if (lds) return count ? render_kernel<true, true, 1024, MODE> : render_kernel<true, false, 1024, MODE>;
+        return count ? render_kernel<false, true, 1024, MODE> : render_kernel<false, false, 1024, MODE>;
     }
     if (block == 768) {
-        if (lds) return count ? render_kernel<true, true, 768> : render_kernel<true, false, 768>;
-        return count ? render_kernel<false, true, 768> : render_kernel<false, false, 768>;
+        if (lds) return count ? render_kernel<true, true, 768, MODE> : render_kernel<true, false, 768, MODE>;
+        return count ? render_kernel<false, true, 768, MODE> : render_kernel<false, false, 768, MODE>;
     }
     if (block == 512) {
-        if (lds) return count ? render_kernel<true, true, 512> : render_kernel<true, false, 512>;
-        return count ? render_kernel<false, true, 512> : render_kernel<false, false, 512>;
+        if (lds) return count ? render_kernel<true, true, 512, MODE> : render_kernel<true, false, 512, MODE>;
+        return count ? render_kernel<false, true, 512, MODE> : render_kernel<false, false, 512, MODE>;
     }
-    if (lds) return count ? render_kernel<true, true, 256> : render_kernel<true, false, 256>;
-    return count ? render_kernel<false, true, 256> : render_kernel<false, false, 256>;
+    if (lds) return count ? render_kernel<true, true, 256, MODE> : render_kernel<true, false, 256, MODE>;
+    return count ? render_kernel<false, true, 256, MODE> : render_kernel<false, false, 256, MODE>;
+}
+static render_fn pick_kernel(bool lds, bool count, int block, int mode) {
+    return mode == 0 ? pick_mode<0>(lds, count, block) : (mode == 1 ? pick_mode<1>(lds, count, block) : pick_mode<2>(lds, count, block));
 }
 
 extern "C" {
@@ -149,9 +153,15 @@ int rt_set_launch_config(int32_t block_threads, int32_t chunk_pixels, int32_t bl
 
 /* Diagnostic: wave-level stage executions of the last render with RT_RENDER_COUNTERS on this process:
  * refill stages, node trips, leaf stages, shade stages, lanes refilled, lanes shaded. */
-int rt_last_stage_stats(uint64_t out[6]) {
+int rt_last_stage_stats(uint64_t out[9]) {
     if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
-    for (int i = 0; i < 6; ++i) out[i] = g_last_stage_stats[i];
+    for (int i = 0; i < 9; ++i) out[i] = g_last_stage_stats[i];
+    return RT_OK;
+}
+
+int rt_set_passes(int32_t passes) {
+    if (passes < 0 || passes > 2) return fail(RT_ERR_INVALID_ARGUMENT, "passes must be 0 (auto), 1 (fused) or 2 (two-pass)");
+    g_passes = passes;
     return RT_OK;
 }
 
@@ -289,7 +299,7 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     p.queue = (unsigned int *) (scr + 128);
 
     const size_t ldsBytes = (lds ? (size_t) h.off.total : 0u) + (size_t) (block / 64) * RTD_WAVE_WORDS(chunk) * 4u;
-    render_fn fn = pick_kernel(lds, count, block);
+    render_fn fn = pick_kernel(lds, count, block, 0);
     HIP_TRY(hipFuncSetAttribute((const void *) fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes));
     int perCu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, (const void *) fn, block, ldsBytes));
@@ -297,10 +307,17 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     if (g_blocks_per_cu > 0 && g_blocks_per_cu < perCu) perCu = g_blocks_per_cu;
     const uint64_t nLocal = (uint64_t) n_rows * (uint64_t) p.cols;
     const uint64_t units = (nLocal + (uint64_t) chunk - 1) / (uint64_t) chunk;
-    uint64_t grid = (uint64_t) ds->cu_count * (uint64_t) perCu;
+    const uint64_t fullGrid = (uint64_t) ds->cu_count * (uint64_t) perCu;
+    uint64_t grid = fullGrid;
     const uint64_t wavesPerBlock = (uint64_t) block / 64u;
     const uint64_t needBlocks = (units + wavesPerBlock - 1) / wavesPerBlock;
     if (grid > needBlocks) grid = needBlocks;
+    // Few units per wave => the fused kernel ends with most waves waiting for a few long units (a 16-pixel unit on a glass sphere
+    // takes tens of ms): render in two passes with the second one ordered longest-job-first.  Many units per wave => the fused
+    // kernel's tail is ~2 % and it saves the second launch.  spp <= 2k+1 has no second phase at all.
+    const int n2 = camera->samples_per_pixel - 2 * p.k - 1;
+    const bool twoPass = n2 > 0 && nLocal > 0 && nLocal < (1ull << 32) &&
+                         (g_passes == 2 || (g_passes == 0 && units < 40ull * fullGrid * wavesPerBlock));
 
     struct Events { // destroyed on every exit path
         hipEvent_t a = nullptr, b = nullptr;
@@ -314,8 +331,56 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     HIP_TRY(hipMemsetAsync(scr, 0, RT_SCRATCH_BYTES, st));
     if (grid > 0) {
         if (stats) HIP_TRY(hipEventRecord(ev0, st));
-        hipLaunchKernelGGL(fn, dim3((unsigned) grid), dim3((unsigned) block), ldsBytes, st, p);
-        HIP_TRY(hipGetLastError());
+        if (!twoPass) {
+            hipLaunchKernelGGL(fn, dim3((unsigned) grid), dim3((unsigned) block), ldsBytes, st, p);
+            HIP_TRY(hipGetLastError());
+        } else {
+            // stream-ordered workspace: pairs[nLocal] u64, list[nLocal] u32, hist/offsets/cursor[64] u32
+            unsigned char *ws = nullptr;
+            const size_t pairsBytes = (size_t) nLocal * 8u, listBytes = ((size_t) nLocal * 4u + 15u) & ~(size_t) 15u, sortBytes = 3u * RTD_COST_BUCKETS * 4u;
+            HIP_TRY(hipMallocAsync((void **) &ws, pairsBytes + listBytes + sortBytes, st));
+            unsigned int *sortBuf = (unsigned int *) (ws + pairsBytes + listBytes);
+            hipError_t e = hipMemsetAsync(sortBuf, 0, sortBytes, st);
+            p.pairs = (unsigned long long *) ws;
+            p.live_list = (const unsigned int *) (ws + pairsBytes);
+            p.queue_b = (unsigned long long *) (scr + 136);
+            p.live_count = (unsigned int *) (scr + 144);
+            p.total_waves = (uint32_t) (fullGrid * wavesPerBlock);
+            render_fn fa = pick_kernel(lds, count, block, 1), fb = pick_kernel(lds, count, block, 2);
+            // Unit sizes: pass A traces only 2k+1 samples per pixel, so its units are wide; pass B's largest unit is about a
+            // sixteenth of a wave's share of the shard (measured best: 32 px at 1/2 frame, 16 at 1/4, 8 at 1/8 of config 3),
+            // and shrinks towards the end of the cost-ordered list.
+            int chunkA = g_chunk_pixels ? g_chunk_pixels : 32, chunkB = g_chunk_pixels ? g_chunk_pixels : 4;
+            if (!g_chunk_pixels) {
+                const uint64_t share = nLocal / (fullGrid * wavesPerBlock * 16u);
+                while (chunkB < 32 && (uint64_t) chunkB * 2u <= share) chunkB *= 2;
+            }
+            while (chunkA > 1 && !lds_fits(h, block, chunkA) && lds) chunkA /= 2;
+            const size_t ldsA = (lds ? (size_t) h.off.total : 0u) + (size_t) (block / 64) * RTD_WAVE_WORDS(chunkA) * 4u;
+            const size_t ldsB = (lds ? (size_t) h.off.total : 0u) + (size_t) (block / 64) * RTD_WAVE_WORDS(chunkB) * 4u;
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *) fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsA);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *) fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsB);
+            if (e == hipSuccess) {
+                RenderParams pa = p;
+                pa.chunk = chunkA;
+                const uint64_t unitsA = (nLocal + (uint64_t) chunkA - 1) / (uint64_t) chunkA;
+                uint64_t gridA = (unitsA + wavesPerBlock - 1) / wavesPerBlock;
+                if (gridA > fullGrid) gridA = fullGrid;
+                hipLaunchKernelGGL(fa, dim3((unsigned) gridA), dim3((unsigned) block), ldsA, st, pa);
+                p.chunk = chunkB;
+                hipLaunchKernelGGL(sort_hist_kernel, dim3(256), dim3(256), 0, st, (const unsigned long long *) p.pairs, (const unsigned int *) p.live_count,
+                                   (uint32_t) (2 * p.k + 1), sortBuf);
+                hipLaunchKernelGGL(sort_offsets_kernel, dim3(1), dim3(64), 0, st, (const unsigned int *) sortBuf, sortBuf + RTD_COST_BUCKETS);
+                hipLaunchKernelGGL(sort_scatter_kernel, dim3(256), dim3(256), 0, st, (const unsigned long long *) p.pairs, (const unsigned int *) p.live_count,
+                                   (uint32_t) (2 * p.k + 1), (const unsigned int *) (sortBuf + RTD_COST_BUCKETS), sortBuf + 2 * RTD_COST_BUCKETS,
+                                   (unsigned int *) (ws + pairsBytes));
+                hipLaunchKernelGGL(fb, dim3((unsigned) fullGrid), dim3((unsigned) block), ldsB, st, p);
+                e = hipGetLastError();
+            }
+            const hipError_t ef = hipFreeAsync(ws, st);
+            if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("two-pass launch: ") + hipGetErrorString(e));
+            if (ef != hipSuccess) return fail(RT_ERR_HIP, std::string("hipFreeAsync: ") + hipGetErrorString(ef));
+        }
         if (stats) HIP_TRY(hipEventRecord(ev1, st));
     }
     if (stats) {
@@ -323,6 +388,9 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
         unsigned long long c[16] = {0};
         HIP_TRY(hipMemcpy(c, scr, sizeof(c), hipMemcpyDeviceToHost));
         for (int i = 0; i < 6; ++i) g_last_stage_stats[i] = c[8 + i];
+        g_last_stage_stats[6] = c[14];                                  // sum of wave lifetimes, 100 MHz ticks
+        g_last_stage_stats[7] = c[15] - (0x4000000000000000ull - c[7]); // first wave start -> last wave end, ticks
+        g_last_stage_stats[8] = (unsigned long long) (twoPass ? fullGrid : grid) * (unsigned long long) wavesPerBlock;
         float ms = 0.f;
         if (grid > 0) HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         memset(stats, 0, sizeof(*stats));

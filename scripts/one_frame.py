@@ -29,7 +29,7 @@ for _ in range(a.launches):
     print({k: st[k] for k in ("kernel_ms", "rays", "aabb_tests", "prim_tests", "samples")}, flush=True)
     if a.counters:
         import ctypes
-        ss = (ctypes.c_uint64 * 6)()
+        ss = (ctypes.c_uint64 * 9)()
         rt.lib.rt_last_stage_stats(ss)
         names = ("refill_stages", "node_trips", "leaf_stages", "shade_stages", "lanes_refilled", "lanes_shaded")
         print(dict(zip(names, list(ss))), flush=True)

@@ -406,3 +406,25 @@ def test_config5_full_geometry_row(rt, orc):
     differing = np.count_nonzero(np.any(res.accum != acc, axis=-1))
     assert differing <= 4, differing
     assert set(np.unique(res.accum[..., 0])) <= {11, 2000}
+
+
+@pytest.mark.parametrize("chunk", [0, 1, 5, 64])
+def test_two_pass_rendering_equals_fused(rt, orc, chunk):
+    """rt_set_passes: phase 1 + decision as one launch, a cost-ordered list, phase 2 as another (used for small shards) gives
+    the very same integers as the fused kernel and the oracle, counters included."""
+    objs, cam, w, h = scenes.small_final(spp=30, pixels=10)
+    s = rt.Scene.make(objs)
+    acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=6, threads=8)
+    try:
+        rt.set_launch_config(0, chunk)
+        for passes in (1, 2):
+            rt.set_passes(passes)
+            _assert_render_equal(s.render_rows(w, h, cam, seed=6, counters=True), acc, rgb, st)
+        objs2, cam2, w2, h2 = scenes.all_materials(pixels=9)
+        rt.set_passes(2)
+        res = rt.Scene.make(objs2).render_rows(w2, h2, cam2, seed=8, row_first=1, row_stride=2, counters=True)
+        acc2, rgb2, st2 = orc.OracleScene(objs2).render_rows(w2, h2, cam2.to_abi(), seed=8, row_first=1, row_stride=2, threads=8)
+        _assert_render_equal(res, acc2, rgb2, st2)
+    finally:
+        rt.set_passes(0)
+        rt.set_launch_config(0, 0)
