@@ -97,3 +97,30 @@ def test_empty_scene_is_allowed(rt):
     s = rt.Scene.make([])
     info = s.info()
     assert info["n_bounded"] == 0 and info["n_nodes"] == 0 and info["n_unbounded"] == 0
+
+
+def _build_c_smoke(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(ROOT, "ray-tracing-fsharp_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "abi_smoke.c"),
+                           "-L", libdir, "-lrtfs_amd", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe])
+    return exe
+
+
+def test_header_is_plain_c99_and_a_c_program_can_use_the_abi(tmp_path):
+    """include/rtfs_amd.h must be consumable from C (a P/Invoke or cgo maintainer reads it as C): syntax-check it as C99 with
+    -pedantic, then build and run tests/c/abi_smoke.c (host-side entry points; the render call must refuse without a GPU)."""
+    import subprocess
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "rtfs_amd.h")])
+    out = subprocess.run([_build_c_smoke(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "host checks ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_program_renders_on_the_gpu(tmp_path):
+    import subprocess
+    out = subprocess.run([_build_c_smoke(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rendered 7x7 px" in out.stdout
