@@ -2,18 +2,19 @@
 //
 // Takes the role of Scene.render / renderPixel / traceOnce / traceRay (Scene.fs:93-236) for one shard of image rows.
 //
-// Execution model (DESIGN.md "Kernel"):
-//   * One workgroup per CU-slot, scene image staged ONCE per workgroup into LDS (<= ~140 KiB), then every WAVE is an
-//     independent worker: it pulls a work unit of `chunk` consecutive pixels from a global queue (one atomic per unit).
-//   * Inside a unit the 64 lanes are path slots.  A lane whose path ended takes the next (pixel, sample) item of the
-//     unit (wave ballot + mbcnt rank: "refill"), so lanes never idle while the unit has samples left, and a wave always
-//     runs ONE bounce for all live lanes per loop trip.
-//   * Adaptive sampling (Scene.fs:172-194) is done per unit: phase 1 traces 2k+1 samples of every pixel, splitting the
-//     byte sums at sample k+1; the wave then compares the two integer means per pixel, ballot-compacts the pixels that
-//     must continue, and phase 2 traces their remaining spp-2k-1 samples.
-//   * Per-sample colours are summed with LDS atomics into the wave's own accumulator slots; each pixel's PixelStats
-//     {Count,SumRed,SumGreen,SumBlue} is written once, as one 16-byte store per lane (coalesced), plus the mean RGB.
-//   No cross-workgroup communication exists, so no fences are needed; the queue counter is a relaxed device atomic.
+// Execution model:
+//   * One workgroup per CU-slot, scene image staged ONCE per workgroup into LDS (<= ~118 KiB at 1024 threads), then every
+//     WAVE is an independent worker pulling work units (runs of pixels) from a global queue, one atomic per unit.
+//   * Inside a unit the 64 lanes are path slots in one of three states (idle / walking the tree / walk finished); stages
+//     (refill, node loop, leaf tests, shade) run when enough lanes want them -- see run_items.
+//   * Adaptive sampling (Scene.fs:172-194): phase 1 traces 2k+1 samples of every pixel, splitting the byte sums after
+//     sample k; the wave compares the two integer means per pixel and ballot-compacts the pixels that must continue;
+//     phase 2 traces their remaining spp-2k-1 samples -- either right away on the same wave (fused mode) or in a second
+//     launch over the surviving pixels ordered longest-job-first (two-pass mode, for small shards) -- see render_kernel.
+//   * Per-sample colours are summed with LDS atomics into the wave's own accumulator words; each pixel's PixelStats
+//     {Count,SumRed,SumGreen,SumBlue} is written as one 16-byte store per lane (coalesced), plus the mean RGB.
+//   No cross-workgroup communication exists inside a launch, so no fences are needed; queues and counters are relaxed
+//   device atomics, and pass B only reads what the stream-ordered earlier launches wrote.
 #pragma once
 #include "rt_device.h"
 
@@ -33,8 +34,8 @@ struct RenderParams {
     int32_t n_rows;
     int32_t k;                     // firstTrial = min 5 (spp/2)   (Scene.fs:172)
     int32_t chunk;                 // pixels per work unit, <= 64
-    int32_t yield_lanes;           // see run_items: stage yield threshold
-    int32_t refill_lanes;          // see run_items: refill threshold
+    int32_t yield_lanes;           // see run_items: a stage yields once this many lanes wait for another stage
+    int32_t refill_lanes;          // see run_items: idle lanes are refilled once this many are idle
     int32_t *accum;                // [n_rows*cols][4]
     uint8_t *rgb;                  // [n_rows*cols][3] or null
     unsigned long long *counters;  // [16]: rays, aabb, prim, refl, samples, pixels_early, -, -, then stage executions (COUNT):
