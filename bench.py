@@ -89,6 +89,11 @@ def cpu_baseline(objs, cam, w, h, seed, target_seconds):
         _, _, st = scene.render_rows(w, h, cam.to_abi(), seed=seed, row_first=first, row_stride=stride, n_rows=n, threads=threads)
         return st, time.perf_counter() - t0, first, n
 
+    # one host thread on a small sample (BASELINE.md 3.2 asks for the 1-thread figure beside the all-cores one)
+    t0 = time.perf_counter()
+    _, _, st1 = scene.render_rows(w, h, cam.to_abi(), seed=seed, row_first=rows // 2, row_stride=max(1, rows // 4), n_rows=2, threads=1)
+    one_thread = st1["rays"] / (time.perf_counter() - t0) / 1e6
+
     cal_stride = max(1, rows // 32)
     st, dt, first, n = run(cal_stride)  # calibration: ~32 rows spread over the frame
     rate = st["rays"] / dt
@@ -96,7 +101,7 @@ def cpu_baseline(objs, cam, w, h, seed, target_seconds):
     stride = max(1, min(cal_stride, int(round(full_rays / max(rate * target_seconds, 1.0)))))
     if stride < cal_stride:
         st, dt, first, n = run(stride)
-    return {"value": round(st["rays"] / dt / 1e6, 4), "unit": "Mray/s", "cores": threads, "hardware_threads": orc.hardware_threads(), "kind": "port",
+    return {"value": round(st["rays"] / dt / 1e6, 4), "unit": "Mray/s", "cores": threads, "hardware_threads": orc.hardware_threads(), "value_1_thread": round(one_thread, 4), "kind": "port",
             "sample": f"{n} of {rows} image rows (every {stride}th from row {first}) of the same frame: {st['rays']} rays in {dt:.1f} s; "
                       f"oracle = C++ restatement of the F# path (the .NET reference cannot run in this image)",
             "rays": st["rays"], "seconds": round(dt, 2)}
@@ -237,6 +242,8 @@ def main():
                     "ray_sphere_tests_per_s": round(job["prim_tests"] / (ms_per_step * 1e-3), 1),
                     "aabb_tests_per_s": round(job["aabb_tests"] / (ms_per_step * 1e-3), 1),
                     "samples_per_s": round(job["samples"] / (ms_per_step * 1e-3), 1),
+                    "primary_rays_per_s": round(job["samples"] / (ms_per_step * 1e-3), 1),
+                    "mean_hits_per_path": round(job["reflections"] / max(1, job["samples"]), 4),
                     "early_exit_fraction": round(job["pixels_early"] / (rows * cols), 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src, "physical_from_same_profile": physical,

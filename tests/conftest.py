@@ -15,6 +15,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def rt():
     import ray_tracing_fsharp_amd as m
+    # optional stress knobs: run the whole suite under another kernel configuration (results must not change)
+    if os.environ.get("RTFS_PASSES"):
+        m.set_passes(int(os.environ["RTFS_PASSES"]))
+    if os.environ.get("RTFS_BLOCK") or os.environ.get("RTFS_CHUNK"):
+        m.set_launch_config(int(os.environ.get("RTFS_BLOCK", "0")), int(os.environ.get("RTFS_CHUNK", "0")))
     return m
 
 
