@@ -55,7 +55,7 @@ struct RenderParams {
 //   pix  [P][4]     row, col, pixel stream key lo, hi
 //   live [P]        compacted pixel slots for phase 2
 //   cost [P]        rays traced for the pixel in phase 1 (pass A only: the cost estimate that orders pass B)
-#define RTD_WAVE_WORDS(P) (12u * (uint32_t) (P))
+#define RTD_WAVE_WORDS(P) (14u * (uint32_t) (P)) /* pass B uses it as two slots of {acc [P][3], pix [P][4]} */
 
 // Wave-private LDS words: adds from many lanes may land on one word (same pixel), so they are ds_add_u32; the owner
 // lane later takes the sum and clears the word in one ds_wrxchg.  One wave's LDS operations execute in order.
@@ -222,6 +222,201 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
     }
 }
 
+// Pass B (MODE 2): phase 2 for the pixels of the cost-ordered list, STREAMED.  A wave reserves a run of list entries ("range"),
+// hands out its npx*n2 items, and while the last paths of that range are still in flight it already reserves the next range and
+// hands out its items: two accumulator slots alternate, a range is flushed (its sums added to what pass A left in `accum`) when
+// its last path has ended.  There is no dependency between ranges, so no lane waits at a range boundary -- which is what makes
+// small ranges (good load balance across waves) affordable.  Lane states and stage scheduling are those of run_items.
+template <bool LDS, bool COUNT>
+RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, RTD_AS3 uint32_t *wv, uint32_t n1, uint32_t n2, Counters &cnt,
+                           StageStats &ss, uint64_t &sampleCount) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t P = (uint32_t) p.chunk;
+    const uint32_t SW = 7u * P; // words per slot: acc [P][3] then pix [P][4]
+    const unsigned long long nList = (unsigned long long) *p.live_count;
+    enum { IDLE = 0, WALK = 1, DONE = 2 };
+    int st = IDLE;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
+    const int end = sc.n_nodes * RTD_NODE_BYTES;
+    Walk w; walk_begin(w); w.off = end;
+    Rng rng; rng.x = rng.y = rng.z = rng.w = 0;
+    uint32_t colour = 0, slotOff = 0; // word offset from wv of the path's accumulator triple (>= SW: slot 1)
+    int bounces = 0;
+
+    // wave-uniform: the range being handed out (cur) and the one draining (prev)
+    unsigned long long curFirst = 0, prevFirst = 0;
+    uint32_t curNpx = 0, curNext = 0, curTotal = 0, curOut = 0, curSlot = 1;
+    uint32_t prevNpx = 0, prevOut = 0, prevSlot = 0;
+    bool exhausted = false;
+
+    auto flush = [&](unsigned long long first, uint32_t npx, uint32_t slot) {
+        RTD_AS3 uint32_t *acc = wv + slot * SW;
+        if ((uint32_t) lane < npx) { // this wave is the only writer of these pixels
+            const unsigned long long lp = (unsigned long long) p.live_list[first + (uint32_t) lane];
+            const i4 prev = ((const i4 *) p.accum)[lp];
+            i4 out;
+            out.x = prev.x + (int) n2;
+            out.y = prev.y + (int) lds_take(acc + lane * 3 + 0);
+            out.z = prev.z + (int) lds_take(acc + lane * 3 + 1);
+            out.w = prev.w + (int) lds_take(acc + lane * 3 + 2);
+            sampleCount += (uint64_t) n2;
+            ((i4 *) p.accum)[lp] = out;
+            if (p.rgb) {
+                p.rgb[lp * 3 + 0] = (uint8_t) (out.y / out.x);
+                p.rgb[lp * 3 + 1] = (uint8_t) (out.z / out.x);
+                p.rgb[lp * 3 + 2] = (uint8_t) (out.w / out.x);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (;;) {
+        // ---- ranges: flush what has drained, reserve the next one when the current one has no items left ----
+        if (prevNpx != 0u && prevOut == 0u) { flush(prevFirst, prevNpx, prevSlot); prevNpx = 0u; }
+        if (curNext >= curTotal && prevNpx == 0u) {
+            if (curNpx != 0u) { // the current range becomes the draining one (or is flushed at once if nothing is in flight)
+                if (curOut == 0u) flush(curFirst, curNpx, curSlot);
+                else { prevFirst = curFirst; prevNpx = curNpx; prevOut = curOut; prevSlot = curSlot; }
+                curNpx = 0u; curNext = curTotal = curOut = 0u;
+            }
+            if (!exhausted) {
+                unsigned long long first = 0;
+                uint32_t npx = 0;
+                if (lane == 0) { // guided self-scheduling over the cost-ordered list: big ranges first, single pixels at the end
+                    const unsigned long long seen = __hip_atomic_load(p.queue_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seen < nList) {
+                        unsigned long long want = (nList - seen) / (2ull * p.total_waves);
+                        want = want < 1ull ? 1ull : (want > (unsigned long long) P ? (unsigned long long) P : want);
+                        first = atomicAdd(p.queue_b, want);
+                        if (first < nList) npx = (uint32_t) ((nList - first < want) ? (nList - first) : want);
+                    }
+                }
+                npx = __builtin_amdgcn_readfirstlane(npx);
+                if (npx == 0u) exhausted = true;
+                else {
+                    first = ((unsigned long long) __builtin_amdgcn_readfirstlane((uint32_t) (first >> 32)) << 32) |
+                            __builtin_amdgcn_readfirstlane((uint32_t) first);
+                    if (prevNpx != 0u) curSlot = prevSlot ^ 1u; // the draining range keeps its slot
+                    RTD_AS3 uint32_t *acc = wv + curSlot * SW;
+                    RTD_AS3 uint32_t *pix = acc + 3u * P;
+                    for (uint32_t i = (uint32_t) lane; i < 3u * P; i += 64u) acc[i] = 0u;
+                    if ((uint32_t) lane < npx) {
+                        const unsigned long long lp = (unsigned long long) p.live_list[first + (uint32_t) lane];
+                        uint32_t lr = (uint32_t) (lp / (unsigned long long) p.cols);
+                        uint32_t c = (uint32_t) (lp - (unsigned long long) lr * (unsigned long long) p.cols);
+                        uint32_t r = (uint32_t) p.row_first + lr * (uint32_t) p.row_stride;
+                        uint64_t pkey = pixel_key(p.seed_key, (uint64_t) r * (uint64_t) p.cols + c); // global pixel index
+                        pix[lane * 4 + 0] = (uint32_t) (p.cam.max_h - (int) r - 1);
+                        pix[lane * 4 + 1] = (uint32_t) ((int) c - p.cam.max_w);
+                        pix[lane * 4 + 2] = (uint32_t) pkey;
+                        pix[lane * 4 + 3] = (uint32_t) (pkey >> 32);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    curFirst = first; curNpx = npx; curNext = 0u; curTotal = npx * n2; curOut = 0u;
+                }
+            }
+        }
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(st == IDLE);
+        if (curNpx == 0u && prevNpx == 0u && exhausted && idle == ~0ull) break;
+
+        // ---- refill from the current range ----
+        {
+            const uint32_t nIdle = (uint32_t) __popcll(idle);
+            const uint32_t avail = curTotal - curNext;
+            if (nIdle != 0u && avail != 0u && ((int) nIdle >= p.refill_lanes || nIdle == 64u)) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
+                if (COUNT) { ss.refill++; ss.refillLanes += nIdle; }
+                const uint32_t take = nIdle < avail ? nIdle : avail;
+                bool started = false;
+                if (st == IDLE && rank < take) {
+                    const uint32_t item = curNext + rank;
+                    const uint32_t j = item / n2;
+                    const uint32_t smp = n1 + (item - j * n2);
+                    const RTD_AS3 uint32_t *pix = wv + curSlot * SW + 3u * P;
+                    const int row = (int) pix[j * 4 + 0], col = (int) pix[j * 4 + 1];
+                    const uint64_t pkey = (uint64_t) pix[j * 4 + 2] | ((uint64_t) pix[j * 4 + 3] << 32);
+                    rng = stream_for(pkey, smp);
+                    slotOff = curSlot * SW + j * 3u;
+                    colour = RTD_WHITE;
+                    bounces = 0;
+                    if (camera_ray(p.cam, row, col, rng, o, d)) {
+                        st = WALK;
+                        walk_begin(w);
+                        started = true;
+                        if (COUNT) cnt.rays++;
+                    }
+                }
+                curNext += take;
+                curOut += (uint32_t) __popcll(__builtin_amdgcn_ballot_w64(started));
+            }
+        }
+        const int nBusy = __popcll(__builtin_amdgcn_ballot_w64(st != IDLE));
+        if (nBusy == 0) continue;
+
+        // ---- walk (as in run_items) ----
+        if (__builtin_amdgcn_ballot_w64(st == WALK) != 0ull) {
+            WalkCtx c = walk_ctx(d, w);
+            const int stop = (nBusy - p.yield_lanes) > 0 ? (nBusy - p.yield_lanes) : 0;
+            for (;;) {
+                for (;;) {
+                    const bool act = w.off < end;
+                    const int nAct = __popcll(__builtin_amdgcn_ballot_w64(act));
+                    if (nAct <= stop) break;
+                    if (COUNT) ss.trips++;
+                    if (act) {
+                        if (COUNT) cnt.aabb++;
+                        node_step<LDS>(sc, o, c, w);
+                    }
+                }
+                if (COUNT && __builtin_amdgcn_ballot_w64((w.off & RTD_LEAF) != 0) != 0ull) ss.leaf++;
+                if (w.off & RTD_LEAF) {
+                    if (COUNT) cnt.prim++;
+                    leaf_test<LDS>(sc, o, d, c, w);
+                }
+                const bool fin = (st == WALK) && (w.off >= end);
+                if (fin) st = DONE;
+                const int nWalk = __popcll(__builtin_amdgcn_ballot_w64(st == WALK));
+                const int nDone = __popcll(__builtin_amdgcn_ballot_w64(st == DONE));
+                if (nWalk == 0 || nDone >= p.yield_lanes) break;
+            }
+        }
+
+        // ---- finish (as in run_items) ----
+        if (COUNT) { const unsigned long long dm = __builtin_amdgcn_ballot_w64(st == DONE); if (dm) { ss.shade++; ss.shadeLanes += (uint32_t) __popcll(dm); } }
+        bool ended = false;
+        if (st == DONE) {
+            unbounded_tests<LDS, COUNT>(sc, o, d, w, cnt);
+            uint32_t result = RTD_BLACK;
+            if (w.best < 0) ended = true;
+            else {
+                V3 strike = walk(o, d, w.bestLen);
+                if (COUNT) cnt.refl++;
+                if (reflection<LDS>(sc, w.best, strike, o, d, colour, rng)) { ended = true; result = colour; }
+                else {
+                    bounces = bounces + 1;
+                    if (bounces > p.cam.depth) { ended = true; result = RTD_HOTPINK; }
+                }
+            }
+            if (ended) {
+                if (result != 0u) {
+                    lds_add(wv + slotOff + 0, result & 0xFFu);
+                    lds_add(wv + slotOff + 1, (result >> 8) & 0xFFu);
+                    lds_add(wv + slotOff + 2, (result >> 16) & 0xFFu);
+                }
+                st = IDLE;
+                w.off = end;
+            } else {
+                st = WALK;
+                walk_begin(w);
+                if (COUNT) cnt.rays++;
+            }
+        }
+        const bool inCur = (curNpx != 0u) && ((slotOff >= SW) == (curSlot == 1u));
+        curOut -= (uint32_t) __popcll(__builtin_amdgcn_ballot_w64(ended && inCur));
+        prevOut -= (uint32_t) __popcll(__builtin_amdgcn_ballot_w64(ended && !inCur));
+    }
+}
+
 // MODE 0: fused -- a unit's pixels go through phase 1, the adaptive decision and phase 2 on one wave.
 // MODE 1: pass A -- phase 1 and the decision for every pixel; pixels that continue are appended to `pairs` with the number of
 //         rays their 2k+1 samples took (a cost estimate), the others are final.
@@ -262,12 +457,14 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     uint32_t earlyCount = 0;
     uint64_t sampleCount = 0; // Scene.traceOnce calls = sum of PixelStats.Count
 
-    const unsigned long long nList = (MODE == 2) ? (unsigned long long) *p.live_count : 0ull;
+    if (MODE == 2) run_stream<LDS, COUNT>(p, sc, wv, n1, n2, cnt, ss, sampleCount);
+    else
     for (;;) {
         unsigned long long first = 0;
         uint32_t npx = 0;
         if (MODE == 2) {
-            if (lane == 0) { // guided self-scheduling over the cost-ordered list: big units first, single pixels at the end
+            const unsigned long long nList = 0ull; // (pass B runs run_stream; this branch is dead code kept for the template)
+            if (lane == 0) {
                 const unsigned long long seen = __hip_atomic_load(p.queue_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (seen < nList) {
                     unsigned long long want = (nList - seen) / (2ull * p.total_waves);

@@ -353,7 +353,7 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
             int chunkA = g_chunk_pixels ? g_chunk_pixels : 32, chunkB = g_chunk_pixels ? g_chunk_pixels : 4;
             if (!g_chunk_pixels) {
                 const uint64_t share = nLocal / (fullGrid * wavesPerBlock * 16u);
-                while (chunkB < 32 && (uint64_t) chunkB * 2u <= share) chunkB *= 2;
+                while (chunkB < 32 && (uint64_t) chunkB * 3u / 2u <= share) chunkB *= 2; // nearest power of two
             }
             while (chunkA > 1 && !lds_fits(h, block, chunkA) && lds) chunkA /= 2;
             const size_t ldsA = (lds ? (size_t) h.off.total : 0u) + (size_t) (block / 64) * RTD_WAVE_WORDS(chunkA) * 4u;
