@@ -23,7 +23,10 @@ namespace rtd {
 #define RTD_MAX_CHUNK 64
 
 struct RenderParams {
-    CameraParams cam;
+    const CameraParams *cam_ptr;   // device copy of the camera: read where a camera ray is built, not held in SGPRs
+    int32_t depth;                 // Camera.BounceDepth
+    int32_t spp;                   // Camera.SamplesPerPixel
+    int32_t max_w, max_h;
     SceneOffsets off;
     const unsigned char *scene_image; // global copy of the image described by `off`
     const TexRec *tex;
@@ -141,7 +144,9 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
                 slotOff = (((s < split) ? 0u : (uint32_t) p.chunk * 3u) + slot * 3u) | (slot << 16); // low half: acc word, high half: pixel slot
                 colour = RTD_WHITE;
                 bounces = 0;
-                if (camera_ray(p.cam, row, col, rng, o, d)) {
+                const CameraParams *cp = p.cam_ptr;
+                asm volatile("" : "+s"(cp)); // keep the camera's 32 dwords out of the loop-carried SGPR set
+                if (camera_ray(*cp, row, col, rng, o, d)) {
                     st = WALK;
                     walk_begin(w);
                     if (COUNT) cnt.rays++;
@@ -200,7 +205,7 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
                 if (reflection<LDS>(sc, w.best, strike, o, d, colour, rng)) { done = true; result = colour; }
                 else {
                     bounces = bounces + 1;
-                    if (bounces > p.cam.depth) { done = true; result = RTD_HOTPINK; } // Scene.fs:98,114
+                    if (bounces > p.depth) { done = true; result = RTD_HOTPINK; } // Scene.fs:98,114
                 }
             }
             if (done) {
@@ -306,8 +311,8 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, RTD_
                         uint32_t c = (uint32_t) (lp - (unsigned long long) lr * (unsigned long long) p.cols);
                         uint32_t r = (uint32_t) p.row_first + lr * (uint32_t) p.row_stride;
                         uint64_t pkey = pixel_key(p.seed_key, (uint64_t) r * (uint64_t) p.cols + c); // global pixel index
-                        pix[lane * 4 + 0] = (uint32_t) (p.cam.max_h - (int) r - 1);
-                        pix[lane * 4 + 1] = (uint32_t) ((int) c - p.cam.max_w);
+                        pix[lane * 4 + 0] = (uint32_t) (p.max_h - (int) r - 1);
+                        pix[lane * 4 + 1] = (uint32_t) ((int) c - p.max_w);
                         pix[lane * 4 + 2] = (uint32_t) pkey;
                         pix[lane * 4 + 3] = (uint32_t) (pkey >> 32);
                     }
@@ -339,7 +344,9 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, RTD_
                     slotOff = curSlot * SW + j * 3u;
                     colour = RTD_WHITE;
                     bounces = 0;
-                    if (camera_ray(p.cam, row, col, rng, o, d)) {
+                    const CameraParams *cp = p.cam_ptr;
+                    asm volatile("" : "+s"(cp));
+                    if (camera_ray(*cp, row, col, rng, o, d)) {
                         st = WALK;
                         walk_begin(w);
                         started = true;
@@ -394,7 +401,7 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, RTD_
                 if (reflection<LDS>(sc, w.best, strike, o, d, colour, rng)) { ended = true; result = colour; }
                 else {
                     bounces = bounces + 1;
-                    if (bounces > p.cam.depth) { ended = true; result = RTD_HOTPINK; }
+                    if (bounces > p.depth) { ended = true; result = RTD_HOTPINK; }
                 }
             }
             if (ended) {
@@ -448,7 +455,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     const uint64_t nLocal = (uint64_t) p.n_rows * (uint64_t) p.cols;
     const uint32_t k = (uint32_t) p.k;
     const uint32_t n1 = 2u * k + 1u;
-    const int n2s = p.cam.spp - 2 * p.k - 1; // Scene.fs:191
+    const int n2s = p.spp - 2 * p.k - 1; // Scene.fs:191
     const uint32_t n2 = n2s > 0 ? (uint32_t) n2s : 0u;
 
     const unsigned long long tStart = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -494,8 +501,8 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
             uint32_t c = (uint32_t) (lp - (unsigned long long) lr * (unsigned long long) p.cols);
             uint32_t r = (uint32_t) p.row_first + lr * (uint32_t) p.row_stride;
             uint64_t pkey = pixel_key(p.seed_key, (uint64_t) r * (uint64_t) p.cols + c); // global pixel index
-            pix[lane * 4 + 0] = (uint32_t) (p.cam.max_h - (int) r - 1);
-            pix[lane * 4 + 1] = (uint32_t) ((int) c - p.cam.max_w);
+            pix[lane * 4 + 0] = (uint32_t) (p.max_h - (int) r - 1);
+            pix[lane * 4 + 1] = (uint32_t) ((int) c - p.max_w);
             pix[lane * 4 + 2] = (uint32_t) pkey;
             pix[lane * 4 + 3] = (uint32_t) (pkey >> 32);
         }

@@ -50,12 +50,12 @@ struct DeviceScene {
     unsigned char *image = nullptr;
     TexRec *tex = nullptr;
     uint8_t *texels = nullptr;
-    unsigned char *scratch = nullptr; // ring of 256-byte {counters[16], queue} slots
+    unsigned char *scratch = nullptr; // ring of 512-byte {counters[16], queues, camera} slots
     unsigned next_slot = 0;
     int cu_count = 0;
 };
 #define RT_SCRATCH_SLOTS 64
-#define RT_SCRATCH_BYTES 256
+#define RT_SCRATCH_BYTES 512
 
 struct rt_scene {
     rth::HostScene host;
@@ -264,17 +264,21 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     if (!lds && block > 256 && lds_fits(h, 256, chunk)) { block = 256; lds = true; }
 
     RenderParams p{};
+    CameraParams hostCam{};
     for (int a = 0; a < 3; ++a) {
-        p.cam.eye[a] = camera->view_origin[a];
-        p.cam.xo[a] = camera->xaxis_origin[a];
-        p.cam.xd[a] = camera->xaxis_dir[a];
-        p.cam.yd[a] = camera->yaxis_dir[a];
+        hostCam.eye[a] = camera->view_origin[a];
+        hostCam.xo[a] = camera->xaxis_origin[a];
+        hostCam.xd[a] = camera->xaxis_dir[a];
+        hostCam.yd[a] = camera->yaxis_dir[a];
     }
-    p.cam.vw = camera->viewport_width;
-    p.cam.vh = camera->viewport_height;
-    p.cam.max_w = max_w; p.cam.max_h = max_h;
-    p.cam.spp = camera->samples_per_pixel;
-    p.cam.depth = camera->bounce_depth;
+    hostCam.vw = camera->viewport_width;
+    hostCam.vh = camera->viewport_height;
+    hostCam.max_w = max_w; hostCam.max_h = max_h;
+    hostCam.spp = camera->samples_per_pixel;
+    hostCam.depth = camera->bounce_depth;
+    p.max_w = max_w; p.max_h = max_h;
+    p.spp = camera->samples_per_pixel;
+    p.depth = camera->bounce_depth;
     p.off = h.off;
     p.scene_image = ds->image;
     p.tex = ds->tex;
@@ -297,6 +301,7 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     unsigned char *scr = ds->scratch + (size_t) slot * RT_SCRATCH_BYTES;
     p.counters = (unsigned long long *) scr;
     p.queue = (unsigned int *) (scr + 128);
+    p.cam_ptr = (const CameraParams *) (scr + 256);
 
     const size_t ldsBytes = (lds ? (size_t) h.off.total : 0u) + (size_t) (block / 64) * RTD_WAVE_WORDS(chunk) * 4u;
     render_fn fn = pick_kernel(lds, count, block, 0);
@@ -328,7 +333,8 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
         HIP_TRY(hipEventCreate(&ev.b));
     }
     hipEvent_t &ev0 = ev.a, &ev1 = ev.b;
-    HIP_TRY(hipMemsetAsync(scr, 0, RT_SCRATCH_BYTES, st));
+    HIP_TRY(hipMemsetAsync(scr, 0, 256, st));
+    HIP_TRY(hipMemcpyAsync(scr + 256, &hostCam, sizeof(hostCam), hipMemcpyHostToDevice, st)); // pageable source: copied before return
     if (grid > 0) {
         if (stats) HIP_TRY(hipEventRecord(ev0, st));
         if (!twoPass) {
