@@ -186,8 +186,8 @@ def main():
     # the counters of one launch (deterministic for a seed): an untimed replica with the counting kernel variant
     st = rtd.render_shard_device(scene, cam, w, h, args.seed, local_rank, first, stride, n, local, stream=stream.cuda_stream,
                                  counters=True, want_stats=True)
-    if world > 1:
-        step()  # untimed, whatever --warmup says: the first gather sets up RCCL's peer-to-peer connections over xGMI
+    step()  # untimed, whatever --warmup says: first launch of the timed kernel variant, stream-ordered pool set-up, and (N>1)
+            # the first gather, which sets up RCCL's peer-to-peer connections over xGMI
     for _ in range(args.warmup):
         step()
     fence()
