@@ -1,0 +1,215 @@
+"""oracle/oracle.cpp against tests/fsharp_literal.py, an independent line-by-line Python transliteration of the same F# source
+(recursive tree walk, mutable Ray objects, ValueOption as None).  Two restatements written in different styles agreeing bit
+for bit on every function and on whole renders is the strongest pin available for the parts of the path the reference has
+no tests for (Scene.*, BoundingBoxTree.make, InfinitePlane.*, Lambert/Pure/Fuzzed reflection).
+CPU only; pure-Python path tracing, so the images are a few pixels across."""
+import dataclasses
+import math
+
+import numpy as np
+import pytest
+
+import fsharp_literal as L
+import scenes
+from ray_tracing_fsharp_amd import _abi as A
+
+rt_mod = scenes.rt
+P, V, S, PS, H, Px, Tex = scenes.P, scenes.V, scenes.S, scenes.PS, scenes.H, scenes.Px, scenes.Tex
+
+SPHERE_STYLES = {A.RT_SPHERE_LIGHT_SOURCE: "LightSource", A.RT_SPHERE_LIGHT_SOURCE_CAP: "LightSourceCap", A.RT_SPHERE_PURE_REFLECTION: "Pure",
+                 A.RT_SPHERE_FUZZED_REFLECTION: "Fuzzed", A.RT_SPHERE_LAMBERT_REFLECTION: "Lambert", A.RT_SPHERE_DIELECTRIC: "Dielectric",
+                 A.RT_SPHERE_GLASS: "Glass"}
+PLANE_STYLES = {A.RT_PLANE_LIGHT_SOURCE: "LightSource", A.RT_PLANE_PURE_REFLECTION: "Pure", A.RT_PLANE_FUZZED_REFLECTION: "Fuzzed",
+                A.RT_PLANE_LAMBERT_REFLECTION: "Lambert"}
+
+
+def to_literal(objects):
+    """Host-mirror Hittables (solid colours only) -> the dicts fsharp_literal works on."""
+    out = []
+    for h in objects:
+        if h.kind == A.RT_HITTABLE_INFINITE_PLANE:
+            st = h.plane.Style
+            rgb = tuple(st.texture.pixel) if st.style == A.RT_PLANE_LIGHT_SOURCE else tuple(st.colour)
+            out.append({"kind": "plane", "style": PLANE_STYLES[st.style], "rgb": rgb, "albedo": st.albedo, "fuzz": st.fuzz,
+                        "normal": tuple(h.plane.Normal), "point": tuple(h.plane.Point)})
+        else:
+            st = h.sphere.Style
+            rgb = tuple(st.colour) if st.style == A.RT_SPHERE_LIGHT_SOURCE_CAP else tuple(st.texture.pixel)
+            out.append({"kind": "sphere" if h.kind == A.RT_HITTABLE_SPHERE else "usphere", "style": SPHERE_STYLES[st.style], "rgb": rgb,
+                        "albedo": st.albedo, "fuzz": st.fuzz, "ior": st.ior, "prob": st.prob, "centre": tuple(h.sphere.Centre),
+                        "radius": h.sphere.Radius})
+    return out
+
+
+def literal_camera(cam):
+    a = cam.abi
+    return {"eye": tuple(a.view_origin), "xo": tuple(a.xaxis_origin), "xd": tuple(a.xaxis_dir), "yd": tuple(a.yaxis_dir),
+            "vw": a.viewport_width, "vh": a.viewport_height, "spp": cam.SamplesPerPixel, "depth": cam.BounceDepth}
+
+
+def literal_render(objects, cam, max_w, max_h, seed):
+    out = L.render(L.scene_make(to_literal(objects)), L.make_stream_for(seed), literal_camera(cam), max_w, max_h)
+    return np.array(out, dtype=np.int64)  # [rows, cols, {Count, SumRed, SumGreen, SumBlue}]
+
+
+def solid_scene(seed):
+    """Like scenes.random_scene, solid colours only (textures have their own parity tests): every style, bounded and
+    unbounded spheres of either sign, planes anywhere, a sky sphere most of the time, the camera possibly inside things."""
+    rng = np.random.default_rng(seed)
+    u = lambda a, b: float(rng.uniform(a, b))  # noqa: E731
+    col = lambda: Px(*(int(x) for x in rng.integers(0, 256, 3)))  # noqa: E731
+    objs = []
+    for _ in range(int(rng.integers(2, 10))):
+        c, r = P(u(-2, 2), u(-1, 2), u(0, 5)), u(0.1, 1.2) * (-1.0 if rng.random() < 0.15 else 1.0)
+        st = [S.LightSource(Tex(col())), S.LightSourceCap(col()), S.PureReflection(u(0, 1), Tex(col())), S.FuzzedReflection(u(0, 1), Tex(col()), u(0, 1)),
+              S.LambertReflection(u(0, 1), Tex(col())), S.Dielectric(u(0, 1), Tex(col()), u(0.7, 2.0), u(0, 1)),
+              S.Glass(u(0.5, 1), Tex(col()), u(0.7, 2.0))][int(rng.integers(0, 7))]
+        objs.append((H.UnboundedSphere if rng.random() < 0.3 else H.Sphere)(rt_mod.Sphere.make(st, c, r)))
+    for _ in range(int(rng.integers(0, 3))):
+        n = rng.normal(size=3)
+        st = [PS.LightSource(Tex(col())), PS.PureReflection(u(0, 1), col()), PS.LambertReflection(u(0, 1), col()),
+              PS.FuzzedReflection(u(0, 1), col(), u(0, 1))][int(rng.integers(0, 4))]
+        objs.append(H.InfinitePlane(rt_mod.InfinitePlane.make(st, P(u(-3, 3), u(-3, 3), u(-3, 6)), scenes.unit(*n))))
+    if rng.random() < 0.7:
+        objs.append(H.UnboundedSphere(rt_mod.Sphere.make(S.LightSource(Tex(col())), P(0.0, 0.0, 0.0), u(20.0, 300.0))))
+    rng.shuffle(objs)
+    d = rng.normal(size=3)
+    cam = dataclasses.replace(rt_mod.Camera.makeBasic(int(rng.integers(1, 26)), u(0.5, 3.0), u(0.8, 2.0), P(u(-1, 1), u(-0.5, 1.5), u(-3, 1)),
+                                                      scenes.unit(*d), V(0.0, 1.0, 0.05)), BounceDepth=int(rng.integers(0, 20)))
+    return list(objs), cam, int(rng.integers(2, 9)), int(rng.integers(2, 7))
+
+
+def bits(a):
+    return np.asarray(a, np.float64).view(np.uint64)
+
+
+def test_float_producer_and_seeding(orc):
+    for seed, pixel, sample in [(0, 0, 0), (7, 123456, 3), (2 ** 63 + 5, 2401 * 1601 - 1, 499), (12345678901234567890, 1, 0)]:
+        st = orc.stream_state(seed, [pixel], [sample])[0]
+        fp = L.make_stream_for(seed)(pixel, sample)
+        assert [fp.x, fp.y, fp.z, fp.w] == [int(v) for v in st]
+        want = orc.float_producer(st, 64)
+        got = [fp.Get() for _ in range(64)]
+        assert np.array_equal(bits(got), bits(want))
+
+
+def test_intersections_bit_exact(orc):
+    rng = np.random.default_rng(11)
+    n = 3000
+    rays = scenes.random_rays(n, 3)
+    rays[: n // 6, 3:] = np.eye(3)[rng.integers(0, 3, n // 6)] * rng.choice([-1.0, 1.0], (n // 6, 1))  # axis-aligned: zero components
+    lo = rng.normal(size=(n, 3)) * 2.0
+    boxes = np.concatenate([lo, lo + rng.uniform(0.0, 3.0, (n, 3))], axis=1)
+    aim = (boxes[n // 2:, :3] + boxes[n // 2:, 3:]) / 2.0 + rng.normal(size=(n - n // 2, 3)) * 0.8 - rays[n // 2:, :3]  # half aim at their box
+    rays[n // 2:, 3:] = aim / np.linalg.norm(aim, axis=1, keepdims=True)
+    boxes[:50, 3:] = boxes[:50, :3] - 0.5  # inverted boxes (negative-radius spheres)
+    rays[50:100, :3] = boxes[50:100, :3]   # origin on a face: 0 * inf = NaN paths
+    want = orc.bbox_hits(rays, boxes)
+    got = [L.bbox_hits(L.inverse_directions(ray_of(r)), ray_of(r), (tuple(b[:3]), tuple(b[3:]))) for r, b in zip(rays.tolist(), boxes.tolist())]
+    assert np.array_equal(np.array(got, np.int32), want)
+    assert 0.1 < want.mean() < 0.9
+
+    sph = np.concatenate([rng.normal(size=(n, 3)) * 2.0, rng.uniform(-2.0, 3.0, (n, 1))], axis=1)
+    rays[100:150, :3] = sph[100:150, :3] + np.abs(sph[100:150, 3:4]) * rays[100:150, 3:]  # origin on the surface
+    want = orc.sphere_first_intersection(rays, sph)
+    got = [L.sphere_first_intersection({"centre": tuple(s[:3]), "radius": s[3]}, ray_of(r)) for r, s in zip(rays.tolist(), sph.tolist())]
+    assert np.array_equal(bits([NAN_IF_NONE(g) for g in got]), bits(want))
+    assert 0.05 < np.isfinite(want).mean() < 0.95
+
+    nrm = rng.normal(size=(n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    pl = np.concatenate([rng.normal(size=(n, 3)) * 2.0, nrm], axis=1)
+    pl[:40, 3:] = np.cross(rays[:40, 3:], rng.normal(size=(40, 3)))  # ray in the plane: denominator ~ 0
+    pl[:40, 3:] /= np.linalg.norm(pl[:40, 3:], axis=1, keepdims=True)
+    want = orc.plane_intersection(rays, pl)
+    got = [L.plane_intersection({"point": tuple(p[:3]), "normal": tuple(p[3:])}, ray_of(r)) for r, p in zip(rays.tolist(), pl.tolist())]
+    assert np.array_equal(bits([NAN_IF_NONE(g) for g in got]), bits(want))
+
+
+def ray_of(r):
+    return L.Ray(tuple(r[:3]), tuple(r[3:]))
+
+
+def NAN_IF_NONE(x):
+    return math.nan if x is None else x
+
+
+def test_pixel_arithmetic_exhaustive_slices(orc):
+    a = np.stack(np.meshgrid(np.arange(256), np.arange(256), indexing="ij"), -1).reshape(-1, 2).astype(np.uint8)
+    pa, pb = np.repeat(a[:, :1], 3, 1), np.repeat(a[:, 1:], 3, 1)
+    want = orc.pixel_combine(pa, pb)[:, 0]
+    got = [L.pixel_combine((int(x), 0, 0), (int(y), 0, 0))[0] for x, y in a]
+    assert np.array_equal(np.array(got, np.uint8), want)
+    alb = np.concatenate([np.linspace(0.0, 1.0, 101), [0.5, 0.1, 0.3, 0.7, 0.9, 1.0 / 3.0, 2.0 / 3.0]])  # x.5 products: half-to-even
+    for al in alb:
+        p = np.repeat(np.arange(256, dtype=np.uint8)[:, None], 3, 1)
+        want = orc.pixel_darken(p, np.full(256, al))[:, 0]
+        got = [L.pixel_darken(float(al), (v, 0, 0))[0] for v in range(256)]
+        assert np.array_equal(np.array(got, np.uint8), want), al
+
+
+def test_tree_shape(orc):
+    """BoundingBoxTree.make: the literal's recursive tree, flattened in pre-order, equals the oracle's pre-order arrays
+    (same leaves in the same order, same boxes bit for bit)."""
+    objs, _cam, _w, _h = scenes.small_final(seed=3, pixels=4)
+    lit = to_literal([h for h in objs if h.kind != A.RT_HITTABLE_INFINITE_PLANE and (h.sphere.Style.texture is None or h.sphere.Style.texture.pixel is not None)])
+    lit_scene = L.scene_make(lit)
+    bounded = [h for h in lit if h["kind"] == "sphere"]
+    flat = []
+
+    def walk(t):
+        if t[0] == "Leaf":
+            flat.append((next(i for i, h in enumerate(bounded) if h is t[1]), t[2]))
+        else:
+            flat.append((-1, t[3]))
+            walk(t[1])
+            walk(t[2])
+
+    walk(lit_scene["BoundingBoxes"])
+    solid = [h for h in objs if h.kind != A.RT_HITTABLE_INFINITE_PLANE and (h.sphere.Style.texture is None or h.sphere.Style.texture.pixel is not None)]
+    _skip, prim, boxes, _d = orc.OracleScene(solid).tree()
+    assert len(flat) == len(prim) > 900
+    assert [p for p, _ in flat] == [int(p) for p in prim]
+    got = np.array([[b[0][0], b[1][0], b[0][1], b[1][1], b[0][2], b[1][2]] for _, b in flat])  # get_tree's order: lo/hi per axis
+    assert np.array_equal(bits(got), bits(boxes))
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_solid_scenes_render_identically(orc, seed):
+    objs, cam, mw, mh = solid_scene(1000 + seed)
+    got = literal_render(objs, cam, mw, mh, seed=seed)
+    accum, _rgb, _st = orc.OracleScene(objs).render_rows(mw, mh, cam.to_abi(), seed=seed)
+    assert np.array_equal(got, accum.astype(np.int64)), f"scene {seed}"
+
+
+def test_every_material_in_one_frame(orc):
+    """A hand-made frame where each style is certainly exercised, including total internal reflection (ior < 1 shell) and
+    HotPink (two facing mirrors with depth 3)."""
+    cam = dataclasses.replace(rt_mod.Camera.makeBasic(14, 1.0, 1.5, P(0.0, 0.2, -1.5), scenes.unit(0.0, 0.0, 1.0), V(0.0, 1.0, 0.0)), BounceDepth=6)
+    objs = [
+        H.Sphere(rt_mod.Sphere.make(S.Glass(0.95, Tex(rt_mod.Colour.White), 1.5), P(-0.9, 0.0, 1.0), 0.5)),
+        H.UnboundedSphere(rt_mod.Sphere.make(S.Glass(1.0, Tex(rt_mod.Colour.White), 1.0 / 1.5), P(-0.9, 0.0, 1.0), -0.4)),
+        H.Sphere(rt_mod.Sphere.make(S.Dielectric(0.9, Tex(Px(200, 255, 200)), 1.4, 0.6), P(0.0, 0.0, 1.0), 0.4)),
+        H.Sphere(rt_mod.Sphere.make(S.FuzzedReflection(0.8, Tex(Px(255, 100, 0)), 0.5), P(0.9, 0.0, 1.0), 0.5)),
+        H.Sphere(rt_mod.Sphere.make(S.LambertReflection(0.7, Tex(Px(25, 50, 120))), P(0.0, 0.9, 1.4), 0.4)),
+        H.Sphere(rt_mod.Sphere.make(S.PureReflection(0.9, Tex(Px(250, 250, 250))), P(0.0, -0.8, 0.8), 0.3)),
+        H.Sphere(rt_mod.Sphere.make(S.LightSourceCap(Px(255, 240, 200)), P(-0.2, 1.8, 1.0), 0.5)),
+        H.InfinitePlane(rt_mod.InfinitePlane.make(PS.PureReflection(1.0, rt_mod.Colour.White), P(0.0, 0.0, 3.0), scenes.unit(0.0, 0.0, -1.0))),
+        H.InfinitePlane(rt_mod.InfinitePlane.make(PS.PureReflection(1.0, rt_mod.Colour.White), P(0.0, 0.0, -3.0), scenes.unit(0.0, 0.0, 1.0))),
+        H.InfinitePlane(rt_mod.InfinitePlane.make(PS.LambertReflection(0.6, Px(120, 220, 120)), P(0.0, -1.2, 0.0), scenes.unit(0.0, 1.0, 0.0))),
+        H.InfinitePlane(rt_mod.InfinitePlane.make(PS.FuzzedReflection(0.85, Px(255, 200, 200), 0.4), P(-2.5, 0.0, 0.0), scenes.unit(1.0, 0.0, 0.0))),
+        H.InfinitePlane(rt_mod.InfinitePlane.make(PS.LightSource(Tex(Px(230, 230, 255))), P(0.0, 3.0, 0.0), scenes.unit(0.0, -1.0, 0.0))),
+    ]
+    got = literal_render(objs, cam, 7, 5, seed=99)
+    accum, _rgb, st = orc.OracleScene(objs).render_rows(7, 5, cam.to_abi(), seed=99)
+    assert np.array_equal(got, accum.astype(np.int64))
+    assert st["samples"] == int(got[..., 0].sum()) and st["reflections"] > 2 * st["samples"]
+
+
+def test_final_scene_thumbnail(orc):
+    """Config 3's scene (483 spheres, the 965-node tree) through the recursive walk, a few pixels, full bounce depth."""
+    objs, cam, mw, mh = scenes.small_final(seed=7, spp=12, depth=50, pixels=6)
+    assert all(h.sphere.Style.texture.pixel is not None for h in objs)
+    got = literal_render(objs, cam, mw, mh, seed=5)
+    accum, _rgb, _st = orc.OracleScene(objs).render_rows(mw, mh, cam.to_abi(), seed=5)
+    assert np.array_equal(got, accum.astype(np.int64))
