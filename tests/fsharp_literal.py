@@ -185,6 +185,54 @@ def bbox_hits(inv, ray, box):
     return tMax >= tMin and tMax >= 0.0
 
 
+# ---- Texture.fs -------------------------------------------------------------------------------------------------------
+# Texture = ("Colour", pixel) | ("Arbitrary", point -> pixel); ParameterisedTexture = ("Colour", pixel) |
+# ("Checkered", even, odd, gridSize) | ("Image", rows) | ("Arbitrary", x -> y -> Texture), closures as in F#.
+def facos(x):  # F# `acos` outside [-1, 1] is NaN; math.acos raises instead
+    return math.acos(x) if -1.0 <= x <= 1.0 else NAN
+
+
+def plane_map_inverse(radius, centre):  # Sphere.fs:55-61, curried like the reference's use of it
+    def interpret(p):
+        x, y, z = v_scale(1.0 / radius, v_diff(p, centre))
+        theta = facos(-y)
+        phi = math.atan2(-z, x) + math.pi
+        return (phi / (2.0 * math.pi)), theta / math.pi
+    return interpret
+
+
+def texture_colour_at(point, t):  # Texture.fs:12-15
+    return t[1] if t[0] == "Colour" else t[1](point)
+
+
+def param_colour_at(interpret, t, p):  # Texture.fs:50-67
+    if t[0] == "Colour":
+        return t[1]
+    if t[0] == "Arbitrary":
+        x, y = interpret(p)
+        return texture_colour_at(p, t[1](x, y))
+    if t[0] == "Checkered":
+        _, even, odd, gridSize = t
+        x, y = interpret(p)
+        sine = math.sin(gridSize * x) * math.sin(gridSize * y)
+        if f_compare(sine, 0.0) == "Less":
+            return param_colour_at(interpret, even, p)
+        return param_colour_at(interpret, odd, p)
+    if t[0] == "Image":
+        img = t[1]
+        x, y = interpret(p)
+        x = int((1.0 - x) * float(len(img[0]) - 1))
+        y = int(y * float(len(img) - 1))
+        return img[y][x]
+    raise ValueError(t[0])
+
+
+def to_texture(interpret, texture):  # Texture.fs:69-72
+    if texture[0] == "Colour":
+        return ("Colour", texture[1])
+    return ("Arbitrary", lambda p: param_colour_at(interpret, texture, p))
+
+
 # ---- Sphere.fs ---------------------------------------------------------------------------------------------------------
 def pow5(x):  # Math.Pow (x, 5.0): exact fifth power, rounded once
     if not math.isfinite(x):
@@ -245,7 +293,8 @@ def sphere_reflection(s, light, strike, rand):  # Sphere.fs:150-300; returns a P
         if flipped:
             inside = True
             flip_in_place(normal)
-    style, tex = s["style"], s["rgb"]
+    style = s["style"]
+    tex = texture_colour_at(strike, s["tex"]) if "tex" in s else s["rgb"]  # LightSourceCap carries a Pixel, not a Texture
     if style == "LightSource":
         return pixel_combine(light["Colour"], tex)
     if style == "LightSourceCap":
@@ -338,7 +387,7 @@ def plane_pure_outgoing(strike, normal, incoming):  # InfinitePlane.fs:18-38
 def plane_reflection(pl, light, strike, rand):  # InfinitePlane.fs:43-99
     style = pl["style"]
     if style == "LightSource":
-        return pixel_combine(light["Colour"], pl["rgb"])
+        return pixel_combine(light["Colour"], texture_colour_at(strike, pl["tex"]) if "tex" in pl else pl["rgb"])
     newColour = pixel_darken(pl["albedo"], pixel_combine(light["Colour"], pl["rgb"]))
     if style == "Fuzzed":
         pure = plane_pure_outgoing(strike, pl["normal"], light["Ray"])

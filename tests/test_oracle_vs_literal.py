@@ -23,21 +23,51 @@ PLANE_STYLES = {A.RT_PLANE_LIGHT_SOURCE: "LightSource", A.RT_PLANE_PURE_REFLECTI
                 A.RT_PLANE_LAMBERT_REFLECTION: "Lambert"}
 
 
+def literal_param(t):
+    """Host-mirror ParameterisedTexture -> the literal's tagged tuples; UvRamp becomes the F# closure it stands for
+    (RayTracing.App/SampleImages.fs:617-636: `byte (float x * 255.0)` per ramped channel)."""
+    if t.kind == A.RT_TEXTURE_COLOUR:
+        return ("Colour", tuple(t.pixel))
+    if t.kind == A.RT_TEXTURE_CHECKERED:
+        return ("Checkered", literal_param(t.even), literal_param(t.odd), t.grid)
+    if t.kind == A.RT_TEXTURE_IMAGE:
+        return ("Image", [[tuple(int(v) for v in px) for px in row] for row in t.image])
+    if t.kind == A.RT_TEXTURE_UV_RAMP:
+        def closure(x, y, t=t):
+            ch = [int(x * 255.0) & 0xFF if src == A.RT_RAMP_U else int(y * 255.0) & 0xFF if src == A.RT_RAMP_V else const
+                  for src, const in zip(t.ramp, t.pixel)]
+            return ("Colour", tuple(ch))
+        return ("Arbitrary", closure)
+    raise ValueError(t.kind)
+
+
+def literal_texture(tex):
+    if tex.pixel is not None:
+        return ("Colour", tuple(tex.pixel))
+    return L.to_texture(L.plane_map_inverse(tex.map_radius, tuple(tex.map_centre)), literal_param(tex.param))
+
+
 def to_literal(objects):
-    """Host-mirror Hittables (solid colours only) -> the dicts fsharp_literal works on."""
+    """Host-mirror Hittables -> the dicts fsharp_literal works on."""
     out = []
     for h in objects:
         if h.kind == A.RT_HITTABLE_INFINITE_PLANE:
             st = h.plane.Style
-            rgb = tuple(st.texture.pixel) if st.style == A.RT_PLANE_LIGHT_SOURCE else tuple(st.colour)
-            out.append({"kind": "plane", "style": PLANE_STYLES[st.style], "rgb": rgb, "albedo": st.albedo, "fuzz": st.fuzz,
-                        "normal": tuple(h.plane.Normal), "point": tuple(h.plane.Point)})
+            d = {"kind": "plane", "style": PLANE_STYLES[st.style], "albedo": st.albedo, "fuzz": st.fuzz, "normal": tuple(h.plane.Normal),
+                 "point": tuple(h.plane.Point)}
+            if st.style == A.RT_PLANE_LIGHT_SOURCE:
+                d["tex"] = literal_texture(st.texture)
+            else:
+                d["rgb"] = tuple(st.colour)
         else:
             st = h.sphere.Style
-            rgb = tuple(st.colour) if st.style == A.RT_SPHERE_LIGHT_SOURCE_CAP else tuple(st.texture.pixel)
-            out.append({"kind": "sphere" if h.kind == A.RT_HITTABLE_SPHERE else "usphere", "style": SPHERE_STYLES[st.style], "rgb": rgb,
-                        "albedo": st.albedo, "fuzz": st.fuzz, "ior": st.ior, "prob": st.prob, "centre": tuple(h.sphere.Centre),
-                        "radius": h.sphere.Radius})
+            d = {"kind": "sphere" if h.kind == A.RT_HITTABLE_SPHERE else "usphere", "style": SPHERE_STYLES[st.style], "albedo": st.albedo,
+                 "fuzz": st.fuzz, "ior": st.ior, "prob": st.prob, "centre": tuple(h.sphere.Centre), "radius": h.sphere.Radius}
+            if st.style == A.RT_SPHERE_LIGHT_SOURCE_CAP:
+                d["rgb"] = tuple(st.colour)
+            else:
+                d["tex"] = literal_texture(st.texture)
+        out.append(d)
     return out
 
 
@@ -213,3 +243,17 @@ def test_final_scene_thumbnail(orc):
     got = literal_render(objs, cam, mw, mh, seed=5)
     accum, _rgb, _st = orc.OracleScene(objs).render_rows(mw, mh, cam.to_abi(), seed=5)
     assert np.array_equal(got, accum.astype(np.int64))
+
+
+def test_textured_scenes_render_identically(orc):
+    """Checkered UV ramps and image textures through Texture.colourAt / planeMapInverse: both sides call glibc's acos,
+    atan2 and sin (CPython's math module is libm), so even these agree exactly."""
+    objs, cam, mw, mh = scenes.all_materials(spp=10, depth=8, pixels=6)
+    got = literal_render(objs, cam, mw, mh, seed=3)
+    accum, _rgb, _st = orc.OracleScene(objs).render_rows(mw, mh, cam.to_abi(), seed=3)
+    assert np.array_equal(got, accum.astype(np.int64))
+    for seed in range(12):
+        objs, cam, mw, mh = scenes.random_scene(500 + seed, pixels=5)
+        got = literal_render(objs, cam, mw, mh, seed=seed)
+        accum, _rgb, _st = orc.OracleScene(objs).render_rows(mw, mh, cam.to_abi(), seed=seed)
+        assert np.array_equal(got, accum.astype(np.int64)), seed
