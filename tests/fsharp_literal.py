@@ -146,6 +146,43 @@ def make_orthonormal_spanned_by(r1, r2):
     return (r1.Vector, vec2, r1.Origin)  # V1, V2, Point
 
 
+def v_sum(a, b):  # Point.fs:20
+    return (a[0] + b[0], a[1] + b[1], a[2] + b[2])
+
+
+def v_cross(p, q):  # Point.fs:44-45
+    (x, y, z), (a, b, c) = p, q
+    return (y * c - z * b, z * a - x * c, x * b - a * y)
+
+
+def make_normal_to(point, v):  # Plane.fs:22-36
+    x, y, z = v
+    v1 = (0.0, 0.0, 1.0) if f_equal(z, 0.0) else (1.0, 1.0, (-x - y) / z)
+    v2 = v_unitise(v_cross(v, v1))
+    v1 = v_unitise(v1)
+    return (v1, v2, point)
+
+
+def plane_basis(viewUp, plane):  # Plane.fs:82-98
+    V1, V2, P = plane
+    viewUp = v_unitise(viewUp)
+    v1Component = v_dot(V1, viewUp)
+    v2Component = v_dot(V2, viewUp)
+    v2 = v_unitise(v_sum(v_scale(v1Component, V1), v_scale(v2Component, V2)))
+    v1 = v_unitise(v_sum(v_scale(v2Component, V1), v_scale(-v1Component, V2)))
+    return Ray(P, v1), Ray(P, v2)
+
+
+def camera_make_basic(samplesPerPixel, focalLength, aspectRatio, origin, viewDirection, viewUp):  # Camera.fs:34-59
+    height = 2.0
+    view = Ray(origin, viewDirection)
+    corner = walk_along(view, focalLength)
+    viewPlane = make_normal_to(corner, viewDirection)
+    xAxis, yAxis = plane_basis(viewUp, viewPlane)
+    return {"eye": view.Origin, "view": view.Vector, "xo": xAxis.Origin, "xd": xAxis.Vector, "yo": yAxis.Origin, "yd": yAxis.Vector,
+            "vw": aspectRatio * height, "vh": height, "focal": focalLength, "spp": samplesPerPixel, "depth": 150}
+
+
 # ---- BoundingBox.fs:25-94 ---------------------------------------------------------------------------------------------
 def inverse_directions(ray):
     def inv(c):

@@ -257,3 +257,20 @@ def test_textured_scenes_render_identically(orc):
         got = literal_render(objs, cam, mw, mh, seed=seed)
         accum, _rgb, _st = orc.OracleScene(objs).render_rows(mw, mh, cam.to_abi(), seed=seed)
         assert np.array_equal(got, accum.astype(np.int64)), seed
+
+
+def test_camera_make_basic(orc):
+    """Camera.makeBasic / Plane.makeNormalTo / Plane.basis: literal vs the oracle's and vs the library's host code."""
+    rng = np.random.default_rng(2)
+    cases = [((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), (0.0, 1.0, 0.0)), ((13.0, 2.0, -3.0), tuple(scenes.unit(-13.0, -2.0, 3.0)), (0.0, 1.0, 0.0)),
+             ((1.0, 1.0, 1.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0))]  # the last has view.z = 0: the other makeNormalTo branch
+    for _ in range(40):
+        cases.append((tuple(rng.normal(size=3)), tuple(scenes.unit(*rng.normal(size=3))), tuple(rng.normal(size=3))))
+    for origin, view, up in cases:
+        lit = L.camera_make_basic(17, 1.3, 1.6, origin, view, up)
+        for cam in (orc.camera_make_basic(17, 1.3, 1.6, origin, view, up), rt_mod.Camera.makeBasic(17, 1.3, 1.6, P(*origin), V(*view), V(*up)).abi):
+            got = np.array([*lit["eye"], *lit["view"], *lit["xo"], *lit["xd"], *lit["yo"], *lit["yd"], lit["vw"], lit["vh"], lit["focal"]])
+            want = np.array([*cam.view_origin, *cam.view_dir, *cam.xaxis_origin, *cam.xaxis_dir, *cam.yaxis_origin, *cam.yaxis_dir,
+                             cam.viewport_width, cam.viewport_height, cam.focal_length])
+            assert np.array_equal(bits(got), bits(want)), (origin, view, up)
+            assert (cam.samples_per_pixel, cam.bounce_depth) == (17, 150)
