@@ -139,16 +139,23 @@ RTD_INLINE double pow5(double x) {
 
 // ---- flattened scene ------------------------------------------------------------------------------------
 // Image layout (bytes; every section 16-byte aligned; built by rt_scene.h, staged verbatim into LDS):
-//   node [n_nodes]   56 B  {lo_x, hi_x, lo_y, hi_y, lo_z, hi_z : double; on_hit, on_miss : int32}
-//                          on_miss = BYTE offset of the node to visit when this box is missed (n_nodes*56 = end);
+//   node [n_nodes]   88 B  {hi_x, lo_x, hi_x, hi_y, lo_y, hi_y, hi_z, lo_z, hi_z : double; on_hit, on_miss : int32; 8 B pad}
+//                          Each axis is stored {hi, lo, hi} so that a ray's (near, far) pair is two ADJACENT doubles whichever
+//                          way it travels: +8 for a non-negative inverse direction (lo, hi), +0 for a negative one (hi, lo) --
+//                          one address add and one ds_read2_b64 per axis.  A visit reads 6 of the 9 doubles and the links.
+//                          The pad makes the stride 11 eight-byte LDS slots (odd): lanes sit at unrelated records, and an odd
+//                          stride spreads them over all banks (measured: 80 B 256.0 ms, 88 B 252.9 ms per config-3 frame).
+//                          on_miss = BYTE offset of the node to visit when this box is missed (n_nodes*88 = end);
 //                          on_hit  = byte offset of the next record for a Branch, RTD_LEAF|object index for a Leaf (whose
-//                          successor is on_miss either way).  7 x ds_read_b64 per visit; a 56-B stride spreads
-//                          consecutive records over all 32 eight-byte LDS slots (7 is odd).
+//                          successor is on_miss either way).  The LDS copy holds ABSOLUTE LDS addresses in both links
+//                          (patched when the image is staged), so a walk position is used as an address as it is.
 //   geo  [n_obj][3]  d2    sphere {cx,cy}{cz,r^2}{radius,0} | plane {px,py}{pz,nx}{ny,nz}   48 B/object
 //   meta [n_obj]     i2    {kind|style<<2|flipped<<5, rgb|(texture+1)<<24}                   8 B/object
 //   mat  [n_obj][3]  double {albedo, fuzz|ior, prob}                                       24 B/object
 // Objects: bounded spheres first (tree leaves point at them), then the unbounded list in Scene.make order.
-#define RTD_NODE_BYTES 56
+#ifndef RTD_NODE_BYTES
+#define RTD_NODE_BYTES 88
+#endif
 #define RTD_LEAF 0x40000000 /* flag in on_hit / in a walk offset: a leaf's primitive test is pending */
 struct TexRec { // global memory only
     uint32_t kind;
@@ -181,6 +188,7 @@ template <bool LDS> struct SceneView {
     typename Ptrs<LDS>::i2p meta;
     typename Ptrs<LDS>::dp mat;
     int n_nodes, n_bounded, n_unbounded;
+    int first, end; // walk positions of the root record and of "tree exhausted" (LDS: absolute addresses; else offsets from `node`)
     const TexRec *tex;
     const uint8_t *texels;
 };
@@ -260,7 +268,7 @@ RTD_INLINE double plane_intersection(V3 o, V3 d, V3 p0, V3 n) {
 // from the ray each time a lane (re)enters the node loop.  The order in which a ray sees its leaves never changes, so the
 // strict-`<` tie-breaking of Scene.fs:45-47 is unchanged.
 struct Walk {
-    int off;        // byte offset of the next node record; >= n_nodes*56 when the tree is exhausted or the lane is not walking;
+    int off;        // position of the next node record (SceneView::first ..); >= SceneView::end when the tree is exhausted or the lane is not walking;
                     // RTD_LEAF|object while that leaf's primitive test is pending (then `resume` is where the walk continues)
     int resume;
     int best;       // bestObject (object index) or -1
@@ -268,28 +276,32 @@ struct Walk {
 };
 struct WalkCtx {
     double ix, iy, iz; // BoundingBox.inverseDirections (BoundingBox.fs:25-28)
-    int nX, nY, nZ;    // byte offset of each axis' NEAR plane inside a node record: the swap of BoundingBox.fs:52-55
+    int nX, nY, nZ;    // 0 or 8: byte offset of each axis' (near, far) pair inside its {hi, lo, hi} triple: the swap of BoundingBox.fs:52-55
     double bestF;      // bestFloat = bestLength^2, +inf until something is hit (Scene.fs:65)
 };
-RTD_INLINE void walk_begin(Walk &w) { w.off = 0; w.resume = 0; w.best = -1; w.bestLen = __builtin_nan(""); }
+RTD_INLINE void walk_begin(Walk &w, int first) { w.off = first; w.resume = first; w.best = -1; w.bestLen = __builtin_nan(""); }
 RTD_INLINE WalkCtx walk_ctx(V3 d, const Walk &w) {
     WalkCtx c;
     c.ix = 1.0 / d.x; c.iy = 1.0 / d.y; c.iz = 1.0 / d.z;
-    c.nX = c.ix < 0.0 ? 8 : 0; c.nY = c.iy < 0.0 ? 24 : 16; c.nZ = c.iz < 0.0 ? 40 : 32;
+    c.nX = c.ix < 0.0 ? 0 : 8; c.nY = c.iy < 0.0 ? 0 : 8; c.nZ = c.iz < 0.0 ? 0 : 8;
     c.bestF = (w.best < 0) ? __builtin_inf() : w.bestLen * w.bestLen; // `a = point * point` (Scene.fs:45), recomputed
     return c;
 }
+template <bool LDS> RTD_INLINE typename Ptrs<LDS>::bp node_at(const SceneView<LDS> &sc, int pos);
+template <> RTD_INLINE Ptrs<true>::bp node_at<true>(const SceneView<true> &, int pos) { return (Ptrs<true>::bp) (uintptr_t) (uint32_t) pos; }
+template <> RTD_INLINE Ptrs<false>::bp node_at<false>(const SceneView<false> &sc, int pos) { return sc.node + pos; }
 // One BoundingBox.hits + advance: w.off becomes on_hit or on_miss; a hit Leaf leaves RTD_LEAF|object there.
 template <bool LDS>
 RTD_INLINE void node_step(const SceneView<LDS> &sc, V3 o, const WalkCtx &c, Walk &w) {
     typedef typename Ptrs<LDS>::bp bp;
     typedef typename Ptrs<LDS>::dp dp;
     typedef typename Ptrs<LDS>::i2p i2p;
-    bp rec = sc.node + w.off;
-    const double vnx = *(dp) (rec + c.nX), vfx = *(dp) (rec + (c.nX ^ 8));
-    const double vny = *(dp) (rec + c.nY), vfy = *(dp) (rec + (c.nY ^ 8));
-    const double vnz = *(dp) (rec + c.nZ), vfz = *(dp) (rec + (c.nZ ^ 8));
-    const i2 lk = *(i2p) (rec + 48);
+    bp rec = node_at<LDS>(sc, w.off);
+    bp ax = rec + c.nX, ay = rec + c.nY, az = rec + c.nZ;
+    const double vnx = *(dp) (ax), vfx = *(dp) (ax + 8);
+    const double vny = *(dp) (ay + 24), vfy = *(dp) (ay + 32);
+    const double vnz = *(dp) (az + 48), vfz = *(dp) (az + 56);
+    const i2 lk = *(i2p) (rec + 72);
     const bool hit = bbox_hits_nf(c.ix, c.iy, c.iz, o, vnx, vfx, vny, vfy, vnz, vfz);
     w.off = hit ? lk.x : lk.y;
     w.resume = lk.y;
@@ -331,9 +343,9 @@ template <bool LDS, bool COUNT>
 RTD_INLINE int hit_object(const SceneView<LDS> &sc, V3 o, V3 d, double &bestLen, Counters &cnt) {
     if (COUNT) cnt.rays++;
     Walk w;
-    walk_begin(w);
+    walk_begin(w, sc.first);
     WalkCtx c = walk_ctx(d, w);
-    const int end = sc.n_nodes * RTD_NODE_BYTES;
+    const int end = sc.end;
     for (;;) {
         while (w.off < end) {
             if (COUNT) cnt.aabb++;

@@ -3,7 +3,7 @@
 // Takes the role of Scene.render / renderPixel / traceOnce / traceRay (Scene.fs:93-236) for one shard of image rows.
 //
 // Execution model:
-//   * One workgroup per CU-slot, scene image staged ONCE per workgroup into LDS (<= ~118 KiB at 1024 threads), then every
+//   * One workgroup per CU-slot, scene image staged ONCE per workgroup into LDS (<= ~146 KiB at 1024 threads and 16-pixel units), then every
 //     WAVE is an independent worker pulling work units (runs of pixels) from a global queue, one atomic per unit.
 //   * Inside a unit the 64 lanes are path slots in one of three states (idle / walking the tree / walk finished); stages
 //     (refill, node loop, leaf tests, shade) run when enough lanes want them -- see run_items.
@@ -80,6 +80,7 @@ template <> RTD_INLINE SceneView<true> make_view<true>(const RenderParams &p, co
     v.meta = (Ptrs<true>::i2p) (b + p.off.meta);
     v.mat = (Ptrs<true>::dp) (b + p.off.mat);
     v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
+    v.first = (int) (uint32_t) (uintptr_t) v.node; v.end = v.first + v.n_nodes * RTD_NODE_BYTES; // links were made absolute at staging
     v.tex = p.tex; v.texels = p.texels;
     return v;
 }
@@ -91,6 +92,7 @@ template <> RTD_INLINE SceneView<false> make_view<false>(const RenderParams &p, 
     v.meta = (const i2 *) (b + p.off.meta);
     v.mat = (const double *) (b + p.off.mat);
     v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
+    v.first = 0; v.end = v.n_nodes * RTD_NODE_BYTES;
     v.tex = p.tex; v.texels = p.texels;
     return v;
 }
@@ -120,8 +122,8 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
     enum { IDLE = 0, WALK = 1, DONE = 2 };
     int st = IDLE;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
-    const int end = sc.n_nodes * RTD_NODE_BYTES;
-    Walk w; walk_begin(w); w.off = end; // idle lanes are parked at `end`
+    const int end = sc.end;
+    Walk w; walk_begin(w, sc.first); w.off = end; // idle lanes are parked at `end`
     Rng rng; rng.x = rng.y = rng.z = rng.w = 0;
     uint32_t colour = 0, slotOff = 0;
     int bounces = 0;
@@ -148,7 +150,7 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
                 asm volatile("" : "+s"(cp)); // keep the camera's 32 dwords out of the loop-carried SGPR set
                 if (camera_ray(*cp, row, col, rng, o, d)) {
                     st = WALK;
-                    walk_begin(w);
+                    walk_begin(w, sc.first);
                     if (COUNT) cnt.rays++;
                 }
                 // else: Scene.fs:144's ValueOption.get would throw; the sample counts as Black (adds nothing)
@@ -220,7 +222,7 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
                 w.off = end;
             } else {
                 st = WALK;
-                walk_begin(w);
+                walk_begin(w, sc.first);
                 if (COUNT) cnt.rays++;
             }
         }
@@ -242,8 +244,8 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, RTD_
     enum { IDLE = 0, WALK = 1, DONE = 2 };
     int st = IDLE;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
-    const int end = sc.n_nodes * RTD_NODE_BYTES;
-    Walk w; walk_begin(w); w.off = end;
+    const int end = sc.end;
+    Walk w; walk_begin(w, sc.first); w.off = end;
     Rng rng; rng.x = rng.y = rng.z = rng.w = 0;
     uint32_t colour = 0, slotOff = 0; // word offset from wv of the path's accumulator triple (>= SW: slot 1)
     int bounces = 0;
@@ -348,7 +350,7 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, RTD_
                     asm volatile("" : "+s"(cp));
                     if (camera_ray(*cp, row, col, rng, o, d)) {
                         st = WALK;
-                        walk_begin(w);
+                        walk_begin(w, sc.first);
                         started = true;
                         if (COUNT) cnt.rays++;
                     }
@@ -414,7 +416,7 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, RTD_
                 w.off = end;
             } else {
                 st = WALK;
-                walk_begin(w);
+                walk_begin(w, sc.first);
                 if (COUNT) cnt.rays++;
             }
         }
@@ -446,6 +448,17 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
         __syncthreads();
     }
     const SceneView<LDS> sc = make_view<LDS>(p, smem);
+    if (LDS) { // make the links absolute LDS addresses: a walk position then IS the record's address (no add per visit)
+        RTD_AS3 unsigned char *nodes = (RTD_AS3 unsigned char *) smem + p.off.node;
+        for (int i = threadIdx.x; i < p.off.n_nodes; i += BLOCK) {
+            RTD_AS3 i2 *lk = (RTD_AS3 i2 *) (nodes + i * RTD_NODE_BYTES + 72);
+            i2 v = *lk;
+            if (!(v.x & RTD_LEAF)) v.x += sc.first;
+            v.y += sc.first;
+            *lk = v;
+        }
+        __syncthreads();
+    }
     const uint32_t P = (uint32_t) p.chunk;
     RTD_AS3 uint32_t *wv = (RTD_AS3 uint32_t *) (smem + sceneBytes) + (size_t) wave * RTD_WAVE_WORDS(P);
     RTD_AS3 uint32_t *acc = wv;

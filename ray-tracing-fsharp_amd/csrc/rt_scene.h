@@ -168,7 +168,7 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
     }
     const size_t nb = bounded.size(), nu = unbounded.size(), nobj = nb + nu;
     // walk offsets are int32 byte offsets with bit 30 reserved for the pending-leaf flag (RTD_LEAF)
-    if (nb > 9000000u || nobj > 16000000u) { status = RT_ERR_UNSUPPORTED; return "scene too large for 32-bit walk offsets (9,000,000 bounded spheres)"; }
+    if (nb > 6000000u || nobj > 16000000u) { status = RT_ERR_UNSUPPORTED; return "scene too large for 32-bit walk offsets (6,000,000 bounded spheres)"; } // (2n-1) * 88 B < 2^30
     s.objToOrig.clear();
     s.objToOrig.insert(s.objToOrig.end(), bounded.begin(), bounded.end());
     s.objToOrig.insert(s.objToOrig.end(), unbounded.begin(), unbounded.end());
@@ -209,8 +209,8 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
     double *pmat = (double *) (s.image.data() + off.mat);
     for (size_t i = 0; i < nn; ++i) {
         double *bx = (double *) (pnode + i * RTD_NODE_BYTES);
-        int32_t *lk = (int32_t *) (pnode + i * RTD_NODE_BYTES + 48);
-        for (int a = 0; a < 3; ++a) { bx[a * 2] = s.tree.box[i].mn[a]; bx[a * 2 + 1] = s.tree.box[i].mx[a]; }
+        int32_t *lk = (int32_t *) (pnode + i * RTD_NODE_BYTES + 72);
+        for (int a = 0; a < 3; ++a) { bx[a * 3] = s.tree.box[i].mx[a]; bx[a * 3 + 1] = s.tree.box[i].mn[a]; bx[a * 3 + 2] = s.tree.box[i].mx[a]; }
         const int32_t onMiss = s.tree.skip[i] * RTD_NODE_BYTES; // byte offset of the record to visit on a miss
         lk[0] = s.tree.prim[i] >= 0 ? (int32_t) (RTD_LEAF | s.tree.prim[i]) : (int32_t) ((i + 1) * RTD_NODE_BYTES); // on_hit
         lk[1] = onMiss;
