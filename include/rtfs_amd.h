@@ -258,7 +258,8 @@ int rt_dev_trace_ray(int32_t device, const rt_scene *scene, int32_t bounce_depth
 int rt_dev_texture_colour_at(int32_t device, const rt_scene *scene, int32_t texture, int32_t n, const double *points,
                              double *uv_out, uint8_t *colour_out);
 /* IEEE-754 conformance probes of the device arithmetic the path relies on: op 0: 1.0/x, 1: sqrt(x), 2: rint(x),
- * 3: x/y, 4: pow5(x) = Math.Pow(x, 5.0) (Sphere.fs:290). a,b: n doubles (b may be NULL for unary ops). */
+ * 3: x/y, 4: pow5(x) = Math.Pow(x, 5.0) (Sphere.fs:290), 5: the path's sqrt for operands > 1e-8, 6: its 1.0/sqrt(x) for
+ * operands >= 1e-8 (both must equal the correctly rounded results). a,b: n doubles (b may be NULL for unary ops). */
 int rt_dev_arith(int32_t device, int32_t op, int32_t n, const double *a, const double *b, double *out);
 
 #ifdef __cplusplus

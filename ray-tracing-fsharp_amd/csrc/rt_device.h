@@ -40,11 +40,47 @@ RTD_INLINE V3 vsub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 RTD_INLINE V3 vscale(double s, V3 v) { return mk(s * v.x, s * v.y, s * v.z); }
 // Ray.walkAlongRay (Ray.fs:42-43): o + (v * m) per component
 RTD_INLINE V3 walk(V3 o, V3 v, double m) { return mk(o.x + (v.x * m), o.y + (v.y * m), o.z + (v.z * m)); }
+// Correctly rounded sqrt and reciprocal for operands in the NORMAL range.  The compiler's expansions of sqrt(x) and 1.0/x
+// (v_rsq_f64 / v_rcp_f64 + Newton steps in fma, then one exactly-computed-residual correction -- the sequence that makes the
+// result the correctly rounded one) spend 5 of 18 and 4 of 11 instructions on rescaling denormal / huge operands and on the
+// zero/inf fix-ups.  Every caller below passes a value that has already compared > 1e-8 (or is NaN, which propagates), so the
+// rescaling never triggers and the same arithmetic without it returns the same bits; +inf is restored by the caller's one
+// class test.  tests/test_gpu_parity.py::test_normal_range_sqrt_and_reciprocal checks both against the host's sqrt and
+// division on 40 M operands over [1e-8, 1e300].
+RTD_INLINE double sqrt_core(double x) { // x in [2^-767, 2^1023]: LLVM's f64 sqrt lowering without its input scaling
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double e = fma(-g, g, x);
+    g = fma(e, h, g);
+    e = fma(-g, g, x);
+    return fma(e, h, g);
+}
+RTD_INLINE double rcp_core(double s) { // 1.0 / s for s in [2^-511, 2^511]: LLVM's f64 division lowering without scale and fix-up
+    double r = __builtin_amdgcn_rcp(s);
+    double e = fma(-s, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-s, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-s, r, 1.0); // numerator 1.0: the quotient estimate IS r; residual computed exactly, one last correction
+    return fma(e, r, r);
+}
+RTD_INLINE double sqrt_above_tol(double x) { // sqrt(x) for x > 1e-8 or NaN
+    const double g = sqrt_core(x);
+    return __builtin_isinf(x) ? x : g;
+}
+RTD_INLINE double inv_sqrt_above_tol(double x) { // 1.0 / sqrt(x), both roundings as written, for |x| >= 1e-8 or NaN
+    const double q = rcp_core(sqrt_core(x));
+    return __builtin_isinf(x) ? 0.0 : q; // sqrt(+inf) = +inf, 1.0 / +inf = +0.0
+}
 // Vector.unitise (Point.fs:28-35) == Ray.make' / Ray.overwriteWithMake's direction part (Ray.fs:11-34)
 RTD_INLINE bool unitise(V3 v, V3 &out) {
     double d = dot(v, v);
     if (feq(d, 0.0)) return false;
-    double factor = 1.0 / sqrt(d);
+    double factor = inv_sqrt_above_tol(d); // 1.0 / sqrt d, d >= 1e-8 here
     out = vscale(factor, v);
     return true;
 }
@@ -241,7 +277,7 @@ RTD_INLINE double sphere_first_intersection(V3 o, V3 d, V3 c, double r2) {
     int cmp = fcmp(disc, 0.0);
     if (cmp == CMP_EQ) i = (-b);
     else if (cmp == CMP_GT) {
-        double s = sqrt(disc);
+        double s = sqrt_above_tol(disc); // disc > 1e-8 in this branch
         double i1 = s - b;
         double i2 = -(b + s);
         bool p1 = fpos(i1), p2 = fpos(i2);

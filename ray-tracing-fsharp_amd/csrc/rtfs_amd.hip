@@ -546,7 +546,9 @@ __global__ void k_arith(int op, int n, const double *a, const double *b, double 
     case 1: r = sqrt(a[i]); break;
     case 2: r = rint(a[i]); break;
     case 3: r = a[i] / b[i]; break;
-    default: r = pow5(a[i]); break;
+    case 4: r = pow5(a[i]); break;
+    case 5: r = sqrt_above_tol(a[i]); break;
+    default: r = inv_sqrt_above_tol(a[i]); break;
     }
     out[i] = r;
 }
@@ -730,7 +732,7 @@ int rt_dev_pixel_darken(int32_t device, int32_t n, const uint8_t *p, const doubl
 }
 
 int rt_dev_arith(int32_t device, int32_t op, int32_t n, const double *a, const double *b, double *out) {
-    if (!a || !out || n < 0 || op < 0 || op > 4 || (op == 3 && !b)) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!a || !out || n < 0 || op < 0 || op > 6 || (op == 3 && !b)) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
     int rc = need_device(device);
     if (rc != RT_OK) return rc;
     DevBuf<double> da, db, dout;

@@ -44,6 +44,27 @@ def test_pow5_is_the_correctly_rounded_power(rt, orc):
     assert np.all(np.abs(dev - crt) <= np.spacing(np.abs(crt)))
 
 
+def test_normal_range_sqrt_and_reciprocal(rt):
+    """rt_device.h's sqrt_above_tol / inv_sqrt_above_tol (the compiler's own expansions minus their rescaling of denormal and
+    huge operands) against the host's correctly rounded sqrt and division: 40 M operands log-uniform over [1e-8, 1e300],
+    plus the places rounding is touchiest (perfect squares and their neighbours, values just above the 1e-8 tolerance,
+    powers of two) and the special values (+inf, NaN)."""
+    rng = np.random.default_rng(21)
+    special = np.array([1e-8, 1.0000000000000002e-8, 1.0, 2.0, 4.0, 0.25, 2.0 ** -26, 2.0 ** 600, 1e300, np.inf, np.nan, 3.0, 0.1])
+    ints = rng.integers(1, 2 ** 26, 200000).astype(np.float64)
+    squares = ints * ints
+    near = np.concatenate([squares, np.nextafter(squares, np.inf), np.nextafter(squares, 0.0)])
+    for chunk in range(8):
+        x = np.exp(rng.uniform(np.log(1e-8), np.log(1e300), 5000000))
+        if chunk == 0:
+            x = np.concatenate([x, special, near, 2.0 ** rng.integers(-26, 1000, 4000).astype(np.float64), 1.0 + rng.random(1000000)])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            want_sqrt = np.sqrt(x)
+            want_inv = 1.0 / want_sqrt
+        assert _same_f64(rt.hooks.arith(5, x), want_sqrt)
+        assert _same_f64(rt.hooks.arith(6, x), want_inv)
+
+
 # ---- unit hooks --------------------------------------------------------------------------------------------------
 def test_float_producer_and_stream_state(rt, orc):
     assert _same_f64(rt.hooks.float_producer((1, 2, 3, 4), 1000), orc.float_producer((1, 2, 3, 4), 1000))
