@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
@@ -93,6 +93,7 @@ enum rt_texture_kind {
 };
 
 enum rt_ramp_source { RT_RAMP_CONST = 0, RT_RAMP_U = 1, RT_RAMP_V = 2 };
+enum rt_walk_tree { RT_WALK_TREE_SAH = 0, RT_WALK_TREE_REFERENCE = 1 };
 
 typedef struct rt_texture {
     uint32_t kind;          /* rt_texture_kind */
@@ -131,9 +132,11 @@ typedef struct rt_scene_info {
     int32_t n_bounded;      /* Hittable.Sphere count (leaves of the tree) */
     int32_t n_unbounded;    /* UnboundedSphere + InfinitePlane count, original order kept (Array.partition) */
     int32_t n_nodes;        /* BoundingBoxTree nodes, leaves included (2*n_bounded-1) */
-    int32_t tree_depth;
+    int32_t tree_depth;     /* of BoundingBoxTree.make's tree (what rt_scene_get_tree reports) */
     int32_t n_textures;
     int32_t lds_resident;   /* 1 if the flattened scene fits the 160 KiB LDS image and the LDS kernel is used */
+    int32_t walk_tree;      /* RT_WALK_TREE_*: the tree the device image holds */
+    int32_t walk_tree_depth;
     int64_t scene_bytes;    /* bytes of the flattened device image (without texels) */
     int64_t texel_bytes;
 } rt_scene_info;
@@ -214,6 +217,12 @@ int rt_set_launch_config(int32_t block_threads, int32_t chunk_pixels, int32_t bl
 /* Lane-scheduling thresholds of the render kernel (DESIGN.md "Kernel"): a stage yields once `yield_lanes` lanes wait for
  * another stage; idle lanes are refilled once `refill_lanes` are idle.  0 keeps the default.  Results never depend on them. */
 int rt_set_schedule(int32_t yield_lanes, int32_t refill_lanes);
+/* Which binary tree over the Leaf boxes the device walks, for scenes created AFTERWARDS.  RT_WALK_TREE_SAH (default): a
+ * surface-area-heuristic build, ~14 % fewer box tests per ray on the reference's scenes; RT_WALK_TREE_REFERENCE:
+ * BoundingBoxTree.make's own tree (BoundingBoxTree.fs:9-43), whose box-test count equals the reference's.  The hit a ray
+ * returns -- hence every pixel -- is the same bit for bit under both (rt_scene.h "the tree the device WALKS"); only the
+ * aabb_tests statistic differs. */
+int rt_set_walk_tree(int32_t kind);
 /* 1: always the fused kernel; 2: always two passes (phase 1 + decision, cost-ordered phase 2); 0: choose by shard size.
  * Results never depend on it. */
 int rt_set_passes(int32_t passes);

@@ -29,3 +29,21 @@ def set_passes(passes: int = 0) -> None:
     """0 auto, 1 fused kernel, 2 two-pass (phase 1 + decision, then cost-ordered phase 2).  Never changes a result."""
     from ._lib import check
     check(lib.rt_set_passes(passes))
+
+
+def set_walk_tree(kind="sah") -> None:
+    """Which tree over the Leaf boxes scenes created AFTERWARDS hand to the device: "sah" (default; fewer box tests per ray) or
+    "reference" (BoundingBoxTree.make's own; its box-test count equals the reference's).  Pixels are identical under both."""
+    from . import _abi as A
+    from ._lib import check
+    global _walk_tree
+    k = {"sah": A.RT_WALK_TREE_SAH, "reference": A.RT_WALK_TREE_REFERENCE}.get(kind, kind)
+    check(lib.rt_set_walk_tree(int(k)))
+    _walk_tree = "reference" if int(k) == A.RT_WALK_TREE_REFERENCE else "sah"
+
+
+_walk_tree = "sah"
+
+
+def get_walk_tree() -> str:
+    return _walk_tree

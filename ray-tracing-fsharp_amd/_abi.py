@@ -2,7 +2,7 @@
 tests/test_abi.py checks sizes against the values compiled into the library (rt_abi_sizeof)."""
 import ctypes as C
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 
 RT_OK, RT_ERR_INVALID_ARGUMENT, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_IO = range(6)
 
@@ -16,6 +16,7 @@ RT_PLANE_LIGHT_SOURCE, RT_PLANE_PURE_REFLECTION, RT_PLANE_LAMBERT_REFLECTION, RT
 # rt_texture_kind
 RT_TEXTURE_COLOUR, RT_TEXTURE_CHECKERED, RT_TEXTURE_IMAGE, RT_TEXTURE_UV_RAMP = range(4)
 RT_RAMP_CONST, RT_RAMP_U, RT_RAMP_V = range(3)
+RT_WALK_TREE_SAH, RT_WALK_TREE_REFERENCE = range(2)
 
 RT_RENDER_COUNTERS = 1
 
@@ -57,7 +58,7 @@ class rt_camera(C.Structure):
 class rt_scene_info(C.Structure):
     _fields_ = [
         ("n_bounded", C.c_int32), ("n_unbounded", C.c_int32), ("n_nodes", C.c_int32), ("tree_depth", C.c_int32),
-        ("n_textures", C.c_int32), ("lds_resident", C.c_int32),
+        ("n_textures", C.c_int32), ("lds_resident", C.c_int32), ("walk_tree", C.c_int32), ("walk_tree_depth", C.c_int32),
         ("scene_bytes", C.c_int64), ("texel_bytes", C.c_int64),
     ]
 

@@ -342,14 +342,16 @@ RTD_INLINE void node_step(const SceneView<LDS> &sc, V3 o, const WalkCtx &c, Walk
     w.off = hit ? lk.x : lk.y;
     w.resume = lk.y;
 }
-// Leaf: Hittable.hits (Hittable.fs:27-31) -> Sphere.firstIntersection, kept if t^2 < bestFloat (strict; NaN fails)
+// Leaf: Hittable.hits (Hittable.fs:27-31) -> Sphere.firstIntersection, kept if t^2 < bestFloat (strict; NaN fails).
+// On an exact tie the reference keeps the leaf its depth-first walk met first; object indices are those ranks (rt_scene.h),
+// so the second clause reproduces that when the walked tree visits leaves in another order (and never fires when it does not).
 template <bool LDS>
 RTD_INLINE void leaf_test(const SceneView<LDS> &sc, V3 o, V3 d, WalkCtx &c, Walk &w) {
     const int prim = w.off & (RTD_LEAF - 1);
     const d2 g0 = sc.geo[prim * 3 + 0], g1 = sc.geo[prim * 3 + 1];
     const double t = sphere_first_intersection(o, d, mk(g0.x, g0.y, g1.x), g1.y);
     const double a = t * t;
-    if (a < c.bestF) { c.bestF = a; w.best = prim; w.bestLen = t; }
+    if (a < c.bestF || (a == c.bestF && prim < w.best)) { c.bestF = a; w.best = prim; w.bestLen = t; }
     w.off = w.resume;
 }
 // UnboundedObjects, in array order, accepted only when Float.compare a bestFloat = Less (Scene.fs:77-86)

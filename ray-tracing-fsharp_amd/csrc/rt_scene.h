@@ -91,6 +91,108 @@ class TreeBuilder {
     }
 };
 
+// ---- the tree the device WALKS ------------------------------------------------------------------------------------
+// Scene.bestCandidate tests a sphere iff the ray hits its Leaf box and every box above it (Scene.fs:39-60).  Every Branch box
+// is the exact min/max union of the Leaf boxes below it (BoundingBox.mergeTwo), and (b - o) * inv is monotonic in b even after
+// rounding, so in floating point too a ray that hits a Leaf box hits every box that contains it: the set of spheres tested for
+// a ray is exactly {i : hits leafBox_i}, whatever binary tree of exact unions is put above the leaves.  Among equal t^2 the
+// strict `<` of Scene.fs:47 keeps the first leaf in the reference's depth-first order; with the object table sorted by that
+// rank, `a < best || (a == best && object < bestObject)` reproduces it for any visiting order.  So the device may walk a
+// tree built for fewer box tests -- surface-area heuristic below -- and return the same hit, bit for bit.  The reference's own
+// tree (above) is still built: it defines the ranks, rt_scene_get_tree reports it, and RT_WALK_TREE_REFERENCE walks it
+// (then the box-test counter equals the oracle's as well).
+static inline double half_area(const Box &b) {
+    double d[3];
+    for (int a = 0; a < 3; ++a) { d[a] = b.mx[a] - b.mn[a]; if (!(d[a] > 0.0)) d[a] = 0.0; } // inverted (negative-radius) boxes count as empty
+    return d[0] * d[1] + d[1] * d[2] + d[0] * d[2];
+}
+class SahBuilder {
+  public:
+    SahBuilder(const std::vector<Box> &objBoxes, FlatTree &out) : ob(objBoxes), t(out) {}
+    void build() {
+        std::vector<int32_t> ids(ob.size());
+        for (size_t j = 0; j < ob.size(); ++j) ids[j] = (int32_t) j;
+        suffix.resize(ob.size() + 1);
+        go(ids.data(), ids.size(), 1);
+    }
+
+  private:
+    const std::vector<Box> &ob;
+    FlatTree &t;
+    std::vector<double> suffix;
+    static const size_t kSweepMax = 4096; // above this a node is split on 32 centroid bins per axis instead of a full sweep
+    double centroid2(int32_t id, int axis) const { return ob[(size_t) id].mn[axis] + ob[(size_t) id].mx[axis]; }
+    void sort_axis(int32_t *ids, size_t n, int axis) const {
+        std::sort(ids, ids + n, [&](int32_t a, int32_t b) {
+            const double ca = centroid2(a, axis), cb = centroid2(b, axis);
+            return ca < cb || (ca == cb && a < b);
+        });
+    }
+    void go(int32_t *ids, size_t n, int depth) {
+        if (depth > t.depth) t.depth = depth;
+        Box all = ob[(size_t) ids[0]];
+        for (size_t i = 1; i < n; ++i) all = merge_two(all, ob[(size_t) ids[i]]);
+        const size_t me = t.skip.size();
+        t.skip.push_back(0);
+        t.prim.push_back(n == 1 ? ids[0] : -1);
+        t.box.push_back(all);
+        if (n > 1) {
+            size_t k = n / 2;
+            int bestAxis = -1;
+            if (depth < 48) { // a degenerate input cannot make the recursion deeper than this: below, halve by centroid order
+                double bestCost = 0.0;
+                for (int axis = 0; axis < 3; ++axis) {
+                    if (n <= kSweepMax) {
+                        sort_axis(ids, n, axis);
+                        Box acc = ob[(size_t) ids[n - 1]];
+                        for (size_t i = n - 1; i >= 1; --i) { if (i < n - 1) acc = merge_two(acc, ob[(size_t) ids[i]]); suffix[i] = half_area(acc); }
+                        acc = ob[(size_t) ids[0]];
+                        for (size_t i = 1; i < n; ++i) { // left = ids[0, i), right = ids[i, n); a subtree of m leaves has 2m-1 boxes
+                            if (i > 1) acc = merge_two(acc, ob[(size_t) ids[i - 1]]);
+                            const double cost = half_area(acc) * (double) (2 * i - 1) + suffix[i] * (double) (2 * (n - i) - 1);
+                            if (bestAxis < 0 || cost < bestCost) { bestCost = cost; bestAxis = axis; k = i; }
+                        }
+                    } else {
+                        const int B = 32;
+                        double lo = centroid2(ids[0], axis), hi = lo;
+                        for (size_t i = 1; i < n; ++i) { const double c = centroid2(ids[i], axis); if (c < lo) lo = c; if (c > hi) hi = c; }
+                        if (!(hi > lo)) continue;
+                        Box bb[B]; size_t cnt[B]; bool used[B];
+                        for (int b = 0; b < B; ++b) { cnt[b] = 0; used[b] = false; }
+                        const double scale = (double) B / (hi - lo);
+                        for (size_t i = 0; i < n; ++i) {
+                            int b = (int) ((centroid2(ids[i], axis) - lo) * scale); if (b >= B) b = B - 1; if (b < 0) b = 0;
+                            bb[b] = used[b] ? merge_two(bb[b], ob[(size_t) ids[i]]) : ob[(size_t) ids[i]]; used[b] = true; cnt[b]++;
+                        }
+                        double sufA[B + 1]; size_t sufN[B + 1]; Box acc{}; bool any = false; sufN[B] = 0; sufA[B] = 0.0;
+                        for (int b = B - 1; b >= 0; --b) {
+                            if (used[b]) { acc = any ? merge_two(acc, bb[b]) : bb[b]; any = true; }
+                            sufN[b] = sufN[b + 1] + cnt[b]; sufA[b] = any ? half_area(acc) : 0.0;
+                        }
+                        any = false; size_t nl = 0;
+                        for (int b = 1; b < B; ++b) { // left = bins [0, b)
+                            if (used[b - 1]) { acc = any ? merge_two(acc, bb[b - 1]) : bb[b - 1]; any = true; }
+                            nl += cnt[b - 1];
+                            if (nl == 0 || sufN[b] == 0) continue;
+                            const double cost = half_area(acc) * (double) (2 * nl - 1) + sufA[b] * (double) (2 * sufN[b] - 1);
+                            if (bestAxis < 0 || cost < bestCost) { bestCost = cost; bestAxis = axis; k = nl; }
+                        }
+                    }
+                }
+            }
+            if (bestAxis < 0) { bestAxis = 0; k = n / 2; }
+            if (n <= kSweepMax) { if (bestAxis != 2 || depth >= 48) sort_axis(ids, n, bestAxis); } // ids are in axis-2 order after the sweeps
+            else std::nth_element(ids, ids + k, ids + n, [&](int32_t a, int32_t b) {
+                     const double ca = centroid2(a, bestAxis), cb = centroid2(b, bestAxis);
+                     return ca < cb || (ca == cb && a < b);
+                 });
+            go(ids, k, depth + 1);
+            go(ids + k, n - k, depth + 1);
+        }
+        t.skip[me] = (int32_t) t.skip.size();
+    }
+};
+
 struct HostScene {
     std::vector<rt_hittable> hittables;
     std::vector<rt_texture> textures;
@@ -98,7 +200,9 @@ struct HostScene {
     std::vector<uint8_t> texelBlob;
     std::vector<int32_t> objToOrig; // object-table index -> index in `hittables`
     std::vector<int32_t> origToObj;
-    FlatTree tree;
+    FlatTree tree;     // BoundingBoxTree.make's tree; prim = object-table index (= the leaf's depth-first rank)
+    FlatTree walkTree; // what the device image holds: `tree` itself or the surface-area build over the same leaves
+    int walkKind = RT_WALK_TREE_REFERENCE;
     std::vector<unsigned char> image;
     rtd::SceneOffsets off{};
 };
@@ -108,7 +212,7 @@ static inline uint32_t pack_rgb(const uint8_t rgb[3]) { return (uint32_t) rgb[0]
 static inline size_t align16(size_t v) { return (v + 15u) & ~(size_t) 15u; }
 
 // Returns an empty string on success, otherwise the message for rt_last_error().
-static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture *tex, size_t ntex, HostScene &s, int &status) {
+static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture *tex, size_t ntex, int walk_kind, HostScene &s, int &status) {
     status = RT_ERR_INVALID_ARGUMENT;
     if (n > 0 && !h) return "hittables is NULL";
     if (ntex > 0 && !tex) return "textures is NULL";
@@ -169,19 +273,15 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
     const size_t nb = bounded.size(), nu = unbounded.size(), nobj = nb + nu;
     // walk offsets are int32 byte offsets with bit 30 reserved for the pending-leaf flag (RTD_LEAF)
     if (nb > 6000000u || nobj > 16000000u) { status = RT_ERR_UNSUPPORTED; return "scene too large for 32-bit walk offsets (6,000,000 bounded spheres)"; } // (2n-1) * 88 B < 2^30
-    s.objToOrig.clear();
-    s.objToOrig.insert(s.objToOrig.end(), bounded.begin(), bounded.end());
-    s.objToOrig.insert(s.objToOrig.end(), unbounded.begin(), unbounded.end());
-    s.origToObj.assign(n, -1);
-    for (size_t j = 0; j < nobj; ++j) s.origToObj[(size_t) s.objToOrig[j]] = (int32_t) j;
-
     // ---- Sphere.make's box (Sphere.fs:333-336): centre + (-r,-r,-r) .. centre + (r,r,r); inverted when r < 0 ----
-    std::vector<Box> boxes(nb);
+    std::vector<Box> boxes(nb); // by position in `bounded` (input order), which is what BoundingBoxTree.make receives
+    bool finite = true;
     for (size_t j = 0; j < nb; ++j) {
         const rt_hittable &o = h[(size_t) bounded[j]];
         for (int a = 0; a < 3; ++a) {
             boxes[j].mn[a] = o.point[a] + (-o.radius);
             boxes[j].mx[a] = o.point[a] + o.radius;
+            finite = finite && std::isfinite(boxes[j].mn[a]) && std::isfinite(boxes[j].mx[a]);
         }
     }
     s.tree = FlatTree{};
@@ -190,7 +290,28 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
         for (size_t j = 0; j < nb; ++j) ids[j] = (int32_t) j;
         TreeBuilder(boxes, s.tree).go(ids, 1);
     }
-    const size_t nn = s.tree.skip.size();
+    // Object table: bounded spheres in the order the reference's depth-first walk meets their leaves (so that an object index
+    // IS the tie-breaking rank, see SahBuilder), then the unbounded list in Scene.make order.
+    std::vector<int32_t> rankOf(nb, 0);
+    s.objToOrig.assign(nobj, 0);
+    {
+        int32_t rank = 0;
+        for (size_t i = 0; i < s.tree.prim.size(); ++i)
+            if (s.tree.prim[i] >= 0) { const int32_t j = s.tree.prim[i]; rankOf[(size_t) j] = rank; s.objToOrig[(size_t) rank] = bounded[(size_t) j]; s.tree.prim[i] = rank; ++rank; }
+    }
+    for (size_t u = 0; u < nu; ++u) s.objToOrig[nb + u] = unbounded[u];
+    s.origToObj.assign(n, -1);
+    for (size_t j = 0; j < nobj; ++j) s.origToObj[(size_t) s.objToOrig[j]] = (int32_t) j;
+
+    s.walkKind = (walk_kind == RT_WALK_TREE_REFERENCE || !finite || nb < 3) ? RT_WALK_TREE_REFERENCE : RT_WALK_TREE_SAH;
+    if (s.walkKind == RT_WALK_TREE_SAH) {
+        std::vector<Box> byRank(nb);
+        for (size_t j = 0; j < nb; ++j) byRank[(size_t) rankOf[j]] = boxes[j];
+        s.walkTree = FlatTree{};
+        SahBuilder(byRank, s.walkTree).build();
+    } else s.walkTree = s.tree;
+    const FlatTree &wt = s.walkTree;
+    const size_t nn = wt.skip.size();
 
     // ---- device image ----
     rtd::SceneOffsets &off = s.off;
@@ -210,9 +331,9 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
     for (size_t i = 0; i < nn; ++i) {
         double *bx = (double *) (pnode + i * RTD_NODE_BYTES);
         int32_t *lk = (int32_t *) (pnode + i * RTD_NODE_BYTES + 72);
-        for (int a = 0; a < 3; ++a) { bx[a * 3] = s.tree.box[i].mx[a]; bx[a * 3 + 1] = s.tree.box[i].mn[a]; bx[a * 3 + 2] = s.tree.box[i].mx[a]; }
-        const int32_t onMiss = s.tree.skip[i] * RTD_NODE_BYTES; // byte offset of the record to visit on a miss
-        lk[0] = s.tree.prim[i] >= 0 ? (int32_t) (RTD_LEAF | s.tree.prim[i]) : (int32_t) ((i + 1) * RTD_NODE_BYTES); // on_hit
+        for (int a = 0; a < 3; ++a) { bx[a * 3] = wt.box[i].mx[a]; bx[a * 3 + 1] = wt.box[i].mn[a]; bx[a * 3 + 2] = wt.box[i].mx[a]; }
+        const int32_t onMiss = wt.skip[i] * RTD_NODE_BYTES; // byte offset of the record to visit on a miss
+        lk[0] = wt.prim[i] >= 0 ? (int32_t) (RTD_LEAF | wt.prim[i]) : (int32_t) ((i + 1) * RTD_NODE_BYTES); // on_hit
         lk[1] = onMiss;
     }
     for (size_t j = 0; j < nobj; ++j) {

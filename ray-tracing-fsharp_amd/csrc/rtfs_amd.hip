@@ -66,6 +66,7 @@ struct rt_scene {
 static unsigned long long g_last_stage_stats[9] = {0};
 static int g_block_threads = 0, g_chunk_pixels = 0, g_blocks_per_cu = 0, g_yield_lanes = 0, g_refill_lanes = 0;
 static int g_passes = 0; // 0 auto, 1 fused kernel, 2 two-pass (A, sort, B)
+static int g_walk_tree = RT_WALK_TREE_SAH;
 
 static int device_scene(rt_scene *s, int device, DeviceScene **out) {
     std::lock_guard<std::mutex> lock(s->mu);
@@ -159,6 +160,11 @@ int rt_last_stage_stats(uint64_t out[9]) {
     return RT_OK;
 }
 
+int rt_set_walk_tree(int32_t kind) {
+    if (kind != RT_WALK_TREE_SAH && kind != RT_WALK_TREE_REFERENCE) return fail(RT_ERR_INVALID_ARGUMENT, "walk tree must be RT_WALK_TREE_SAH or RT_WALK_TREE_REFERENCE");
+    g_walk_tree = kind;
+    return RT_OK;
+}
 int rt_set_passes(int32_t passes) {
     if (passes < 0 || passes > 2) return fail(RT_ERR_INVALID_ARGUMENT, "passes must be 0 (auto), 1 (fused) or 2 (two-pass)");
     g_passes = passes;
@@ -184,7 +190,7 @@ int rt_scene_create(const rt_hittable *hittables, size_t n_hittables, const rt_t
     if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
     std::unique_ptr<rt_scene> s(new rt_scene());
     int status = RT_OK;
-    std::string msg = rth::build_scene(hittables, n_hittables, textures, n_textures, s->host, status);
+    std::string msg = rth::build_scene(hittables, n_hittables, textures, n_textures, g_walk_tree, s->host, status);
     if (status != RT_OK) return fail(status, msg);
     *out = s.release();
     return RT_OK;
@@ -209,6 +215,8 @@ int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
     out->n_unbounded = h.off.n_unbounded;
     out->n_nodes = h.off.n_nodes;
     out->tree_depth = h.tree.depth;
+    out->walk_tree = h.walkKind;
+    out->walk_tree_depth = h.walkTree.depth;
     out->n_textures = (int32_t) h.texRecs.size();
     out->lds_resident = lds_fits(h, g_block_threads ? g_block_threads : 1024, g_chunk_pixels ? g_chunk_pixels : 16) ? 1 : 0;
     out->scene_bytes = (int64_t) h.off.total;

@@ -18,6 +18,8 @@ def rt():
     # optional stress knobs: run the whole suite under another kernel configuration (results must not change)
     if os.environ.get("RTFS_PASSES"):
         m.set_passes(int(os.environ["RTFS_PASSES"]))
+    if os.environ.get("RTFS_TREE"):  # "reference": walk BoundingBoxTree.make's own tree (box-test counts then equal the oracle's)
+        m.set_walk_tree(os.environ["RTFS_TREE"])
     if os.environ.get("RTFS_BLOCK") or os.environ.get("RTFS_CHUNK"):
         m.set_launch_config(int(os.environ.get("RTFS_BLOCK", "0")), int(os.environ.get("RTFS_CHUNK", "0")))
     return m

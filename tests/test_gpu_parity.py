@@ -110,6 +110,15 @@ def test_sphere_and_plane_intersection(rt, orc):
     assert _same_f64(rt.hooks.plane_intersection(rays, pl), orc.plane_intersection(rays, pl))
 
 
+def _with_tree(rt, kind, fn):
+    before = rt.get_walk_tree()
+    rt.set_walk_tree(kind)
+    try:
+        return fn()
+    finally:
+        rt.set_walk_tree(before)
+
+
 def _scene_pair(rt, orc, objs):
     return rt.Scene.make(objs), orc.OracleScene(objs)
 
@@ -123,7 +132,11 @@ def test_hit_object_indices_strikes_and_counters(rt, orc):
         h2, s2, c2 = o.hit_object(rays)
         assert np.array_equal(h1, h2)
         assert _same_f64(s1, s2)
-        assert np.array_equal(c1, c2)  # BoundingBox.hits / Hittable.hits call counts per ray
+        assert np.array_equal(c1[:, 1], c2[:, 1])  # Hittable.hits calls per ray: the same leaves whatever tree is walked
+        if rt.get_walk_tree() == "reference":
+            assert np.array_equal(c1[:, 0], c2[:, 0])  # BoundingBox.hits calls per ray
+        else:
+            assert c1[:, 0].sum() < c2[:, 0].sum() or len(objs) < 40
 
 
 def test_reflection_every_style(rt, orc):
@@ -195,8 +208,10 @@ def _render_both(rt, orc, objs, cam, w, h, seed, **shard):
 def _assert_render_equal(res, acc, rgb, st):
     assert np.array_equal(res.accum, acc), f"{np.count_nonzero(np.any(res.accum != acc, axis=-1))} pixels differ"
     assert np.array_equal(res.rgb, rgb)
-    for k in ("rays", "aabb_tests", "prim_tests", "reflections", "samples", "pixels", "pixels_early"):
+    for k in ("rays", "prim_tests", "reflections", "samples", "pixels", "pixels_early"):
         assert res.stats[k] == st[k], k
+    if scenes.rt.get_walk_tree() == "reference":  # the default walks a surface-area tree over the same leaves: fewer box tests
+        assert res.stats["aabb_tests"] == st["aabb_tests"]
 
 
 def test_config1_empty_scene_is_black_with_one_sample(rt, orc):
@@ -315,12 +330,15 @@ def test_hip_reproduces_the_committed_fixtures(rt, name):
 
     g = scenes.golden(name)
     objs, cam, w, h = FIXTURES[name](rt)
-    res = rt.Scene.make(objs).render_rows(w, h, cam, seed=int(g["seed"]), counters=True)
-    if "earth" in name:  # image-texture lookups go through acos/atan2 (OCML vs libm): a texel may flip on an ulp
-        assert np.count_nonzero(np.any(res.accum != g["accum"], axis=-1)) <= 2
-    else:
-        assert np.array_equal(res.accum, g["accum"]) and np.array_equal(res.rgb, g["rgb"])
-        assert [res.stats[k] for k in KEYS] == g["stats"].tolist()
+    for kind in ("sah", "reference"):
+        res = _with_tree(rt, kind, lambda: rt.Scene.make(objs)).render_rows(w, h, cam, seed=int(g["seed"]), counters=True)
+        if "earth" in name:  # image-texture lookups go through acos/atan2 (OCML vs libm): a texel may flip on an ulp
+            assert np.count_nonzero(np.any(res.accum != g["accum"], axis=-1)) <= 2
+        else:
+            assert np.array_equal(res.accum, g["accum"]) and np.array_equal(res.rgb, g["rgb"])
+            want = dict(zip(KEYS, g["stats"].tolist()))
+            for k in KEYS:  # the box-test count is the reference tree's; the default tree needs fewer
+                assert res.stats[k] == want[k] or (k == "aabb_tests" and kind == "sah" and res.stats[k] < want[k]), (kind, k)
 
 
 def test_config5_mixed_scene_thumbnail(rt, orc):
@@ -366,7 +384,73 @@ def test_full_size_config3_properties(rt):
     assert a.stats["samples"] == int(cnt.sum()) and a.stats["pixels_early"] == int((cnt == 11).sum())
     assert np.all(a.accum[0, :, 0] == 11) and np.all(a.accum[0, :, 1:] == np.array([200, 200, 255]) * 11)
     assert a.stats["rays"] == a.stats["reflections"]  # the scene is closed: every ray hits something
-    assert (a.stats["rays"], a.stats["aabb_tests"], a.stats["prim_tests"], a.stats["samples"]) == (3503018818, 98205213022, 11481871042, 1079590420)
+    assert (a.stats["rays"], a.stats["prim_tests"], a.stats["samples"]) == (3503018818, 11481871042, 1079590420)
+    if rt.get_walk_tree() == "reference":
+        assert a.stats["aabb_tests"] == 98205213022  # BoundingBoxTree.make's tree: 28.0 box tests per ray
+    else:
+        assert 0.7 * 98205213022 < a.stats["aabb_tests"] < 0.92 * 98205213022  # the surface-area tree over the same leaves
+        rt.set_walk_tree("reference")
+        try:
+            c = rt.Scene.make(objs).render_rows(w, h, cam, seed=2024, counters=True)
+        finally:
+            rt.set_walk_tree("sah")
+        assert np.array_equal(c.accum, a.accum) and c.stats["aabb_tests"] == 98205213022
+        assert all(c.stats[k] == a.stats[k] for k in ("rays", "prim_tests", "reflections", "samples", "pixels_early"))
+
+
+def test_walk_trees_agree_and_reference_tree_counts_match_oracle(rt, orc):
+    """rt_set_walk_tree: the surface-area tree and BoundingBoxTree.make's own give the same PixelStats and the same
+    rays / leaf tests / reflections / samples; walking the reference's tree, the box-test count equals the oracle's too."""
+    for (objs, cam, w, h), seed in ((scenes.all_materials(), 4), (scenes.small_final(spp=30, pixels=24), 9), (scenes.many_spheres(), 2)):
+        acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=seed, threads=8)
+        got = {}
+        for kind in ("sah", "reference"):
+            s = _with_tree(rt, kind, lambda: rt.Scene.make(objs))
+            assert s.info()["walk_tree"] == {"sah": 0, "reference": 1}[kind] or (kind == "sah" and s.info()["n_bounded"] < 3)
+            got[kind] = s.render_rows(w, h, cam, seed=seed, counters=True)
+            assert np.array_equal(got[kind].accum, acc) and np.array_equal(got[kind].rgb, rgb)
+            for k in ("rays", "prim_tests", "reflections", "samples", "pixels", "pixels_early"):
+                assert got[kind].stats[k] == st[k], (kind, k)
+        assert got["reference"].stats["aabb_tests"] == st["aabb_tests"]
+        assert got["sah"].stats["aabb_tests"] <= st["aabb_tests"]
+    rays = scenes.random_rays(40000, 77, origin_scale=4.0)
+    objs, *_ = scenes.small_final()
+    h2, s2, c2 = orc.OracleScene(objs).hit_object(rays)
+    for kind in ("sah", "reference"):
+        s = _with_tree(rt, kind, lambda: rt.Scene.make(objs))
+        h1, s1, c1 = rt.hooks.hit_object(s, rays)
+        assert np.array_equal(h1, h2) and _same_f64(s1, s2) and np.array_equal(c1[:, 1], c2[:, 1])
+        assert np.array_equal(c1[:, 0], c2[:, 0]) == (kind == "reference")
+
+
+def test_exact_ties_go_to_the_reference_walk_order(rt, orc):
+    """Scene.fs:47's strict `<`: of several spheres hit at exactly the same t^2 the reference keeps the one its depth-first walk
+    meets first.  Coincident spheres (same centre and radius, different colours and styles) among others, in shuffled
+    input order: whichever tree the device walks, the winner -- hence every pixel -- is the oracle's."""
+    S, H, P, Px, Tex = scenes.S, scenes.H, scenes.P, scenes.Px, scenes.Tex
+    rng = np.random.default_rng(5)
+    objs = []
+    for c, r in ((P(0.0, 0.0, 2.0), 0.6), (P(1.0, 0.3, 2.5), 0.5), (P(-1.2, -0.2, 3.0), 0.7)):
+        for k in range(5):  # five coincident copies each
+            col = Px(*(int(x) for x in rng.integers(40, 256, 3)))
+            st = [S.LightSource(Tex(col)), S.LambertReflection(0.8, Tex(col)), S.PureReflection(0.9, Tex(col)), S.Glass(0.9, Tex(col), 1.5),
+                  S.FuzzedReflection(0.7, Tex(col), 0.2)][k]
+            objs.append(H.Sphere(scenes.rt.Sphere.make(st, c, r)))
+    for _ in range(12):
+        objs.append(H.Sphere(scenes.rt.Sphere.make(S.LambertReflection(0.6, Tex(Px(*(int(x) for x in rng.integers(0, 256, 3))))),
+                                                   P(*rng.uniform(-2.5, 2.5, 2), float(rng.uniform(1.0, 4.0))), float(rng.uniform(0.1, 0.4)))))
+    objs.append(H.UnboundedSphere(scenes.rt.Sphere.make(S.LightSource(Tex(Px(210, 220, 255))), P(0.0, 0.0, 0.0), 100.0)))
+    import dataclasses
+    cam = dataclasses.replace(scenes.rt.Camera.makeBasic(16, 1.0, 1.5, P(0.0, 0.0, -1.0), scenes.unit(0.0, 0.0, 1.0), scenes.V(0.0, 1.0, 0.0)), BounceDepth=10)
+    for trial in range(4):
+        order = rng.permutation(len(objs))
+        shuffled = [objs[i] for i in order]
+        acc, rgb, st = orc.OracleScene(shuffled).render_rows(30, 20, cam.to_abi(), seed=trial, threads=8)
+        for kind in ("sah", "reference"):
+            s = _with_tree(rt, kind, lambda: rt.Scene.make(shuffled))
+            res = s.render_rows(30, 20, cam, seed=trial, counters=True)
+            assert np.array_equal(res.accum, acc), (trial, kind)
+            assert res.stats["prim_tests"] == st["prim_tests"] and res.stats["rays"] == st["rays"]
 
 
 def test_scene_larger_than_lds_uses_the_global_memory_kernel(rt, orc):
