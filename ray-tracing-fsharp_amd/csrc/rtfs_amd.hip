@@ -327,12 +327,13 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     if (grid > needBlocks) grid = needBlocks;
     // Few units per wave => the fused kernel ends with most waves waiting for a few long units (a 16-pixel unit on a glass sphere
     // takes tens of ms): render in two passes with the second one ordered longest-job-first.  Many units per wave => the fused
-    // kernel's tail is ~2 % and it saves the second launch.  spp <= 2k+1 has no second phase at all, and with few remaining samples
+    // kernel's tail is ~2 % and it saves the second launch (break-even measured at ~60 units per wave: config 3 whole, 59 per wave,
+    // 221 ms in two passes against 227 ms fused; config 4 whole, 507 per wave, 3.75 s against 3.66 s).  spp <= 2k+1 has no second phase at all, and with few remaining samples
     // per pixel a unit is short, so is the tail, and the second launch costs more than it removes (config 2, 100 spp: fused 3.0 ms,
     // two passes 3.5 ms; config 3's 1/8 shard, 500 spp: 51 ms against 30 ms).
     const int n2 = camera->samples_per_pixel - 2 * p.k - 1;
     const bool twoPass = n2 > 0 && nLocal > 0 && nLocal < (1ull << 32) &&
-                         (g_passes == 2 || (g_passes == 0 && n2 >= 128 && units < 40ull * fullGrid * wavesPerBlock));
+                         (g_passes == 2 || (g_passes == 0 && n2 >= 128 && units < 64ull * fullGrid * wavesPerBlock));
 
     struct Events { // destroyed on every exit path
         hipEvent_t a = nullptr, b = nullptr;

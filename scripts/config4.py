@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import ray_tracing_fsharp_amd as rt
 from ray_tracing_fsharp_amd import distributed as rtd
+rt.set_passes(int(os.environ.get('RTFS_PASSES', '0')))
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8   # render rank 0's shard of `world`
 objs, cam, w, h = rt.sample_images.config3_final(spp=1000, depth=50, pixels=2160)
 w, h = 3840, 2160
