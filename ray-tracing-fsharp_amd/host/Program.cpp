@@ -54,7 +54,8 @@ int main(int argc, char **argv) {
             mix(skip.data(), skip.size() * 4); mix(prim.data(), prim.size() * 4); mix(boxes.data(), boxes.size() * 8);
             std::cout << "bounded=" << si.n_bounded << " unbounded=" << si.n_unbounded << " nodes=" << si.n_nodes << " depth=" << si.tree_depth
                       << " maxW=" << def.maxWidthCoord << " maxH=" << def.maxHeightCoord << " spp=" << def.camera.SamplesPerPixel
-                      << " bounce=" << def.camera.BounceDepth << " tree=" << h << "\n";
+                      << " bounce=" << def.camera.BounceDepth << " tree=" << h << " walk=" << (si.walk_tree == RT_WALK_TREE_SAH ? "sah" : "reference")
+                      << " walkDepth=" << si.walk_tree_depth << "\n";
             return 0;
         }
         auto res = Scene::render(tick, [](const std::string &) {}, def.maxWidthCoord, def.maxHeightCoord, def.camera, scene, seed, device);
