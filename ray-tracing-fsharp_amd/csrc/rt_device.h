@@ -185,9 +185,10 @@ RTD_INLINE double pow5(double x) {
 //                          on_hit  = byte offset of the next record for a Branch, RTD_LEAF|object index for a Leaf (whose
 //                          successor is on_miss either way).  The LDS copy holds ABSOLUTE LDS addresses in both links
 //                          (patched when the image is staged), so a walk position is used as an address as it is.
-//   geo  [n_obj][3]  d2    sphere {cx,cy}{cz,r^2}{radius,0} | plane {px,py}{pz,nx}{ny,nz}   48 B/object
+//   geo  [n_obj][3]  d2    sphere {cx,cy}{cz,r^2}{radius,spare} | plane {px,py}{pz,nx}{ny,nz}   48 B/object
 //   meta [n_obj]     i2    {kind|style<<2|flipped<<5, rgb|(texture+1)<<24}                   8 B/object
-//   mat  [n_obj][3]  double {albedo, fuzz|ior, prob}                                       24 B/object
+//   mat  [n_obj][4]  double {albedo, fuzz|ior, prob, 1/ior} (Dielectric) | {albedo, ior, 1/ior, schlickOutside} (Glass, whose
+//                          schlickInside sits in the sphere record's spare double): per-material values of Sphere.fs:117,283-289   32 B/object
 // Objects: bounded spheres first (tree leaves point at them), then the unbounded list in Scene.make order.
 #ifndef RTD_NODE_BYTES
 #define RTD_NODE_BYTES 88
@@ -454,7 +455,7 @@ RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, 
     const bool isPlane = (m.x & 3) == (int) RTD_KIND_PLANE;
     const int style = (m.x >> 2) & 7;
     const d2 g0 = sc.geo[obj * 3 + 0], g1 = sc.geo[obj * 3 + 1], g2 = sc.geo[obj * 3 + 2];
-    const double albedo = sc.mat[obj * 3 + 0], p1 = sc.mat[obj * 3 + 1], p2 = sc.mat[obj * 3 + 2];
+    const double albedo = sc.mat[obj * 4 + 0], p1 = sc.mat[obj * 4 + 1], p2 = sc.mat[obj * 4 + 2], p3 = sc.mat[obj * 4 + 3];
     uint32_t texColour = (uint32_t) m.y & 0x00FFFFFFu;
     const int texId = (int) (((uint32_t) m.y) >> 24) - 1;
     // Styles that carry a Texture: every SphereStyle but LightSourceCap (Sphere.fs:10-37), and the plane LightSource
@@ -467,6 +468,7 @@ RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, 
     int act = 0;
     double cosI = 0.0; // incomingCos handed to refract
     double ior = p1, fuzz = p1;
+    double invIor = p3; // 1.0 / ior, formed once per material by the host (rt_scene.h) exactly as Sphere.fs:117,284 form it per hit
 
     if (isPlane) {
         n = mk(g1.y, g2.x, g2.y);
@@ -502,9 +504,8 @@ RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, 
         } else {                                                     // Glass, Sphere.fs:269-300
             cosI = dot(vscale(-1.0, d), n);
             double r = rng_get(rng);
-            double sr = inside ? 1.0 / ior : ior;
-            double param = (1.0 - sr) / (1.0 + sr);
-            param = param * param;
+            invIor = p2;
+            const double param = inside ? g2.y : p3; // ((1 - sr) / (1 + sr))^2 for sr = 1/ior | ior (Sphere.fs:283-289), per material
             double prob = param + (1.0 - param) * pow5(1.0 - cosI);
             act = (r < prob) ? ACT_REFLECT : ACT_REFRACT;
         }
@@ -525,7 +526,7 @@ RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, 
     bool haveNv = false, originToStrike = false;
 
     if (act & ACT_REFRACT) { // Sphere.refract (Sphere.fs:108-146)
-        double index = inside ? 1.0 / ior : ior / 1.0;
+        double index = inside ? invIor : ior; // 1.0 / index | index / 1.0 (Sphere.fs:117)
         if (!haveV2) { nv = d; haveNv = true; } // parallel to the normal: straight through, re-normalised (Sphere.fs:121-124)
         else {
             double sinI = sqrt(1.0 - cosI * cosI);

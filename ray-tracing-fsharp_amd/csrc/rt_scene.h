@@ -319,7 +319,7 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
     off.node = (uint32_t) cur; cur = align16(cur + nn * RTD_NODE_BYTES);
     off.geo = (uint32_t) cur;  cur = align16(cur + nobj * 48u);
     off.meta = (uint32_t) cur; cur = align16(cur + nobj * 8u);
-    off.mat = (uint32_t) cur;  cur = align16(cur + nobj * 24u);
+    off.mat = (uint32_t) cur;  cur = align16(cur + nobj * 32u);
     off.total = (uint32_t) cur;
     off.n_nodes = (int32_t) nn; off.n_bounded = (int32_t) nb; off.n_unbounded = (int32_t) nu;
     s.image.assign(cur == 0 ? 16 : cur, 0);
@@ -344,7 +344,7 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
             g[0] = o.point[0]; g[1] = o.point[1]; g[2] = o.point[2];
             g[3] = o.normal[0]; g[4] = o.normal[1]; g[5] = o.normal[2];
             m0 = RTD_KIND_PLANE | (o.style << 2);
-            pmat[j * 3 + 0] = o.albedo; pmat[j * 3 + 1] = o.fuzz; pmat[j * 3 + 2] = 0.0;
+            pmat[j * 4 + 0] = o.albedo; pmat[j * 4 + 1] = o.fuzz; pmat[j * 4 + 2] = 0.0; pmat[j * 4 + 3] = 0.0;
         } else {
             g[0] = o.point[0]; g[1] = o.point[1]; g[2] = o.point[2];
             g[3] = o.radius * o.radius; // RadiusSquared (Sphere.fs:326)
@@ -353,7 +353,21 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
             const bool flipped = !(std::fabs(o.radius - 0.0) < 0.00000001) && (o.radius < 0.0);
             m0 = RTD_KIND_SPHERE | (o.style << 2) | (flipped ? 32u : 0u);
             const bool usesIor = o.style == RT_SPHERE_DIELECTRIC || o.style == RT_SPHERE_GLASS;
-            pmat[j * 3 + 0] = o.albedo; pmat[j * 3 + 1] = usesIor ? o.ior : o.fuzz; pmat[j * 3 + 2] = o.prob;
+            pmat[j * 4 + 0] = o.albedo; pmat[j * 4 + 1] = usesIor ? o.ior : o.fuzz; pmat[j * 4 + 2] = o.prob; pmat[j * 4 + 3] = 0.0;
+            if (usesIor) {
+                // Per-material values the reference recomputes at every hit from the same inputs with the same IEEE operations
+                // (this translation unit is built with -ffp-contract=off): `1.0 / ior` (Sphere.fs:117, 283-284) and Schlick's
+                // `param * param`, param = (1.0 - sr) / (1.0 + sr), for sr = ior (outside) and sr = 1.0 / ior (inside) (Sphere.fs:288-289).
+                const double ior = o.ior;
+                const double inv = 1.0 / ior;
+                if (o.style == RT_SPHERE_DIELECTRIC) pmat[j * 4 + 3] = inv;
+                else {
+                    const double po = (1.0 - ior) / (1.0 + ior), pi = (1.0 - inv) / (1.0 + inv);
+                    pmat[j * 4 + 2] = inv;      // Glass carries no refraction probability
+                    pmat[j * 4 + 3] = po * po;
+                    g[5] = pi * pi;             // the sphere record's spare double
+                }
+            }
         }
         pmeta[j * 2] = (int32_t) m0;
         pmeta[j * 2 + 1] = (int32_t) (pack_rgb(o.rgb) | ((uint32_t) (o.texture + 1) << 24));
