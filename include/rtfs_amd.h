@@ -150,6 +150,10 @@ int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
 /* Flattened tree for inspection/tests: skip[n_nodes], prim[n_nodes] (-1 for Branch), boxes[n_nodes*6] as
  * (minx,maxx,miny,maxy,minz,maxz).  Any pointer may be NULL. */
 int rt_scene_get_tree(const rt_scene *scene, int32_t *skip, int32_t *prim, double *boxes);
+/* The same arrays for the tree the device image holds (rt_set_walk_tree): identical to rt_scene_get_tree's under
+ * RT_WALK_TREE_REFERENCE; under RT_WALK_TREE_SAH another binary tree over the same Leaf boxes, every Branch box again the
+ * exact union of the Leaf boxes below it. */
+int rt_scene_get_walk_tree(const rt_scene *scene, int32_t *skip, int32_t *prim, double *boxes);
 
 /* ---- Render (Scene.render, Scene.fs:196-236) ---------------------------------------------------- */
 typedef struct rt_stats {

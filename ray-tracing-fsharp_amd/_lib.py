@@ -68,6 +68,7 @@ SIGNATURES = {
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_scene_get_info": (C.c_int, [C.c_void_p, _P(A.rt_scene_info)]),
     "rt_scene_get_tree": (C.c_int, [C.c_void_p, _i32p, _i32p, _dp]),
+    "rt_scene_get_walk_tree": (C.c_int, [C.c_void_p, _i32p, _i32p, _dp]),
     "rt_render": (C.c_int, [C.c_void_p, _P(A.rt_camera), C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.c_int32,
                             C.c_int32, C.c_uint32, _i32p, _u8p, _P(A.rt_stats)]),
     "rt_render_device": (C.c_int, [C.c_void_p, _P(A.rt_camera), C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int32,

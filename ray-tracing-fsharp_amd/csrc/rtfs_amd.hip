@@ -224,16 +224,22 @@ int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
     return RT_OK;
 }
 
-int rt_scene_get_tree(const rt_scene *s, int32_t *skip, int32_t *prim, double *boxes) {
-    if (!s) return fail(RT_ERR_INVALID_ARGUMENT, "NULL scene");
-    const rth::HostScene &h = s->host;
-    const size_t nn = h.tree.skip.size();
+static int copy_tree(const rth::HostScene &h, const rth::FlatTree &t, int32_t *skip, int32_t *prim, double *boxes) {
+    const size_t nn = t.skip.size();
     for (size_t i = 0; i < nn; ++i) {
-        if (skip) skip[i] = h.tree.skip[i];
-        if (prim) prim[i] = h.tree.prim[i] < 0 ? -1 : h.objToOrig[(size_t) h.tree.prim[i]];
-        if (boxes) for (int a = 0; a < 3; ++a) { boxes[i * 6 + (size_t) a * 2] = h.tree.box[i].mn[a]; boxes[i * 6 + (size_t) a * 2 + 1] = h.tree.box[i].mx[a]; }
+        if (skip) skip[i] = t.skip[i];
+        if (prim) prim[i] = t.prim[i] < 0 ? -1 : h.objToOrig[(size_t) t.prim[i]];
+        if (boxes) for (int a = 0; a < 3; ++a) { boxes[i * 6 + (size_t) a * 2] = t.box[i].mn[a]; boxes[i * 6 + (size_t) a * 2 + 1] = t.box[i].mx[a]; }
     }
     return RT_OK;
+}
+int rt_scene_get_tree(const rt_scene *s, int32_t *skip, int32_t *prim, double *boxes) {
+    if (!s) return fail(RT_ERR_INVALID_ARGUMENT, "NULL scene");
+    return copy_tree(s->host, s->host.tree, skip, prim, boxes);
+}
+int rt_scene_get_walk_tree(const rt_scene *s, int32_t *skip, int32_t *prim, double *boxes) {
+    if (!s) return fail(RT_ERR_INVALID_ARGUMENT, "NULL scene");
+    return copy_tree(s->host, s->host.walkTree, skip, prim, boxes);
 }
 
 static int check_geometry(const rt_camera *camera, int32_t max_w, int32_t max_h, int32_t row_first, int32_t row_stride, int32_t n_rows) {

@@ -426,6 +426,13 @@ class Scene:
         check(lib.rt_scene_get_tree(self._h, _i32(skip), _i32(prim), _f64(boxes)))
         return skip, prim, boxes
 
+    def walk_tree(self):
+        """The tree the device image holds (rt_set_walk_tree): same arrays as tree()."""
+        n = self.info()["n_nodes"]
+        skip = np.zeros(n, np.int32); prim = np.zeros(n, np.int32); boxes = np.zeros((n, 6), np.float64)
+        check(lib.rt_scene_get_walk_tree(self._h, _i32(skip), _i32(prim), _f64(boxes)))
+        return skip, prim, boxes
+
     def render_rows(self, maxWidthCoord: int, maxHeightCoord: int, camera: Camera, *, seed: int = 0, device: int = 0,
                     row_first: int = 0, row_stride: int = 1, n_rows: Optional[int] = None, counters: bool = False) -> RenderResult:
         """rt_render for the image rows row_first + i*row_stride (the whole frame by default)."""

@@ -453,6 +453,17 @@ def test_exact_ties_go_to_the_reference_walk_order(rt, orc):
             assert res.stats["prim_tests"] == st["prim_tests"] and res.stats["rays"] == st["rays"]
 
 
+def test_six_thousand_spheres_binned_tree_build(rt, orc):
+    """Above 4096 leaves per node the surface-area build switches from a full sweep to 32 centroid bins (rt_scene.h): same bar."""
+    objs, cam, w, h = scenes.many_spheres(n=6000, seed=4, spp=8, depth=6, pixels=8)
+    s = _with_tree(rt, "sah", lambda: rt.Scene.make(objs))
+    assert s.info()["walk_tree"] == 0 and s.info()["lds_resident"] == 0
+    res = s.render_rows(w, h, cam, seed=17, counters=True)
+    acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=17, threads=8)
+    assert np.array_equal(res.accum, acc) and np.array_equal(res.rgb, rgb)
+    assert all(res.stats[k] == st[k] for k in ("rays", "prim_tests", "reflections", "samples")) and res.stats["aabb_tests"] < st["aabb_tests"]
+
+
 def test_scene_larger_than_lds_uses_the_global_memory_kernel(rt, orc):
     """2600 spheres flatten to ~350 KB > 160 KiB of LDS: the LDS=false variant of the render kernel, same bit-exact bar."""
     objs, cam, w, h = scenes.many_spheres()
