@@ -92,3 +92,35 @@ def test_degenerate_inputs_fall_back_or_stay_shallow():
     bad = _spheres(20, seed=3)
     bad[4] = H.Sphere(rt.Sphere.make(S.LambertReflection(0.5, Tex(Px(9, 9, 9))), P(float("inf"), 0.0, 0.0), 0.5))
     assert rt.Scene.make(bad).info()["walk_tree"] == 1
+
+
+def test_a_ray_that_hits_a_box_hits_every_box_containing_it(orc):
+    """The monotonicity the walk-tree argument rests on, checked on the oracle's BoundingBox.hits (the literal restatement of
+    BoundingBox.fs:30-94): 3 M (ray, inner box, outer box) triples with outer = exact union of inner and another box, including
+    axis-parallel rays (infinite inverse directions), origins exactly on faces (0 * inf = NaN paths), origins inside the
+    boxes, shared faces and inverted (negative-radius) boxes.  hits(inner) must imply hits(outer)."""
+    rng = np.random.default_rng(123)
+    n = 3_000_000
+    rays = scenes.random_rays(n, 5, origin_scale=3.0)
+    k = n // 8
+    rays[:k, 3:] = np.eye(3)[rng.integers(0, 3, k)] * rng.choice([-1.0, 1.0], (k, 1))            # axis-parallel
+    two = rng.integers(0, 3, k)
+    rays[k:2 * k, 3:][np.arange(k), two] = 0.0                                                    # one zero component
+    rays[k:2 * k, 3:] /= np.linalg.norm(rays[k:2 * k, 3:], axis=1, keepdims=True)
+    lo = rng.normal(size=(n, 3)) * 2.0
+    inner = np.concatenate([lo, lo + rng.uniform(0.0, 2.0, (n, 3))], axis=1)
+    inner[2 * k:2 * k + 1000, 3:] = inner[2 * k:2 * k + 1000, :3] - 0.3                           # inverted boxes
+    olo = rng.normal(size=(n, 3)) * 2.0
+    other = np.concatenate([olo, olo + rng.uniform(0.0, 2.0, (n, 3))], axis=1)
+    aim = (inner[:, :3] + inner[:, 3:]) / 2.0 + rng.normal(size=(n, 3)) * 0.7 - rays[:, :3]       # half the rays aim at the inner box
+    aim /= np.linalg.norm(aim, axis=1, keepdims=True)
+    sel = rng.random(n) < 0.5
+    sel[:2 * k] = False
+    rays[sel, 3:] = aim[sel]
+    on_face = slice(3 * k, 4 * k)
+    rays[on_face, 0] = inner[on_face, 0]                                                          # origin exactly on the min-x face
+    rays[4 * k:5 * k, :3] = (inner[4 * k:5 * k, :3] + inner[4 * k:5 * k, 3:]) / 2.0               # origin inside
+    outer = np.concatenate([np.minimum(inner[:, :3], other[:, :3]), np.maximum(inner[:, 3:], other[:, 3:])], axis=1)
+    hi, ho = orc.bbox_hits(rays, inner), orc.bbox_hits(rays, outer)
+    assert 0.15 < hi.mean() < 0.85
+    assert not np.any((hi == 1) & (ho == 0))
