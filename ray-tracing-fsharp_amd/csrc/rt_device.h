@@ -269,24 +269,27 @@ RTD_INLINE bool bbox_hits(double ix, double iy, double iz, V3 o, d2 bx, d2 by, d
 }
 
 // ---- Sphere.firstIntersection (Sphere.fs:349-386); returns NaN for ValueNone ----------------------------------------
+// The Greater branch (Sphere.fs:362-380) restated without its Float.compare: i1 = fl(s - b) and i2 = -fl(b + s) with s > 1e-4.
+// Rounding is monotonic and symmetric, so i1 >= i2 always; hence i2 positive implies i1 positive, and when both are positive
+// `Float.compare i1 i2` is Greater (-> i2) unless |i1 - i2| < 1e-8, which -- the difference being ~2s > 2e-4 or, for |b| so
+// large that s is absorbed, a multiple of ulp(b) > 1e-8 -- happens only when i1 == i2 exactly (-> i1, the same double).
+// So the result is i2 if i2 > tol, else i1 if i1 > tol, else none; and the closing `Float.positive` of Sphere.fs:382-386 can
+// only reject the Equal branch's -b.  The oracle keeps the reference's literal control flow; tests compare the two.
 RTD_INLINE double sphere_first_intersection(V3 o, V3 d, V3 c, double r2) {
     V3 diff = vsub(o, c);
     double b = dot(d, diff);
     double cc = dot(diff, diff) - r2;
     double disc = (b * b - cc);
-    double i = __builtin_nan("");
     int cmp = fcmp(disc, 0.0);
-    if (cmp == CMP_EQ) i = (-b);
-    else if (cmp == CMP_GT) {
+    if (cmp == CMP_EQ) { double i = (-b); return fpos(i) ? i : __builtin_nan(""); }
+    double i = __builtin_nan("");
+    if (cmp == CMP_GT) { // also taken by a NaN discriminant, which yields NaN roots and so none
         double s = sqrt_above_tol(disc); // disc > 1e-8 in this branch
         double i1 = s - b;
         double i2 = -(b + s);
-        bool p1 = fpos(i1), p2 = fpos(i2);
-        if (p1 && p2) i = (fcmp(i1, i2) == CMP_GT) ? i2 : i1; // Less -> i1, Greater -> i2, Equal -> i1
-        else if (p1) i = i1;
-        else if (p2) i = i2;
+        i = fpos(i2) ? i2 : (fpos(i1) ? i1 : i);
     }
-    return fpos(i) ? i : __builtin_nan(""); // NaN > tol is false
+    return i;
 }
 
 // ---- InfinitePlane.intersection (InfinitePlane.fs:125-136) -----------------------------------------------------

@@ -110,6 +110,35 @@ def test_sphere_and_plane_intersection(rt, orc):
     assert _same_f64(rt.hooks.plane_intersection(rays, pl), orc.plane_intersection(rays, pl))
 
 
+def test_sphere_roots_across_magnitudes(rt, orc):
+    """The device picks Sphere.firstIntersection's root without the reference's `Float.compare i1 i2` (rt_device.h explains why
+    that is the same double); the oracle keeps the literal control flow.  4 M cases built to sit where the argument is
+    delicate: origins 1e3..1e13 away (the sqrt is absorbed into b, roots differ by 0 or 1 ulp), tangent rays (discriminant in and
+    around the 1e-8 band), origins on, just inside and just outside the surface, tiny and huge radii, rays pointing away."""
+    rng = np.random.default_rng(314)
+    n = 4_000_000
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    c = rng.normal(size=(n, 3)) * 3.0
+    r = np.exp(rng.uniform(np.log(1e-3), np.log(1e4), n)) * rng.choice([-1.0, 1.0], n, p=[0.1, 0.9])
+    dist = np.exp(rng.uniform(np.log(1e-3), np.log(1e13), n))
+    # aim point: centre + offset perpendicular-ish with |offset| around |r| (inside, tangent, outside)
+    off = rng.normal(size=(n, 3))
+    off -= np.sum(off * d, axis=1, keepdims=True) * d
+    off /= np.linalg.norm(off, axis=1, keepdims=True)
+    frac = rng.choice([0.0, 0.5, 0.999999, 1.0, 1.000001, 1.5], n)
+    frac = np.where(rng.random(n) < 0.3, 1.0 + rng.normal(size=n) * 1e-9, frac)
+    aim = c + off * (np.abs(r) * frac)[:, None]
+    o = aim - d * dist[:, None] * rng.choice([1.0, -1.0], n, p=[0.8, 0.2])[:, None]
+    k = n // 10
+    o[:k] = c[:k] + d[:k] * np.abs(r[:k])[:, None] * (1.0 + rng.choice([0.0, 1e-9, -1e-9, 1e-7, -1e-7], k))[:, None]  # on / near the surface
+    rays = np.concatenate([o, d], axis=1)
+    sph = np.concatenate([c, r[:, None]], axis=1)
+    got, want = rt.hooks.sphere_first_intersection(rays, sph), orc.sphere_first_intersection(rays, sph)
+    assert _same_f64(got, want)
+    assert 0.2 < np.isfinite(want).mean() < 0.9
+
+
 def _with_tree(rt, kind, fn):
     before = rt.get_walk_tree()
     rt.set_walk_tree(kind)
