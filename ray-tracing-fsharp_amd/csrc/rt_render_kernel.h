@@ -128,6 +128,8 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
     uint32_t colour = 0, slotOff = 0;
     int bounces = 0;
     uint32_t next = 0; // wave-uniform
+    const bool fastDiv = total < (1u << 22) && per < (1u << 23); // see div_uniform
+    const float perRcp = 1.0f / (float) per;
     for (;;) {
         // ---- refill: idle lanes take the next items of the unit (Scene.traceOnce's ray, Scene.fs:129-150) ----
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(st == IDLE);
@@ -137,7 +139,7 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
             uint32_t item = next + rank;
             if (COUNT) { ss.refill++; ss.refillLanes += (uint32_t) __popcll(idle); }
             if (st == IDLE && item < total) {
-                uint32_t j = item / per;
+                uint32_t j = fastDiv ? div_uniform(item, per, perRcp) : item / per;
                 uint32_t s = s_base + (item - j * per);
                 uint32_t slot = use_live ? live[j] : j;
                 int row = (int) pix[slot * 4 + 0], col = (int) pix[slot * 4 + 1];
@@ -255,6 +257,8 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, RTD_
     uint32_t curNpx = 0, curNext = 0, curTotal = 0, curOut = 0, curSlot = 1;
     uint32_t prevNpx = 0, prevOut = 0, prevSlot = 0;
     bool exhausted = false;
+    const bool fastDiv = (uint64_t) P * (uint64_t) n2 < (1ull << 22) && n2 < (1u << 23); // a range holds at most P * n2 items; see div_uniform
+    const float perRcp = 1.0f / (float) n2;
 
     auto flush = [&](unsigned long long first, uint32_t npx, uint32_t slot) {
         RTD_AS3 uint32_t *acc = wv + slot * SW;
@@ -337,7 +341,7 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, RTD_
                 bool started = false;
                 if (st == IDLE && rank < take) {
                     const uint32_t item = curNext + rank;
-                    const uint32_t j = item / n2;
+                    const uint32_t j = fastDiv ? div_uniform(item, n2, perRcp) : item / n2;
                     const uint32_t smp = n1 + (item - j * n2);
                     const RTD_AS3 uint32_t *pix = wv + curSlot * SW + 3u * P;
                     const int row = (int) pix[j * 4 + 0], col = (int) pix[j * 4 + 1];

@@ -482,6 +482,22 @@ def test_exact_ties_go_to_the_reference_walk_order(rt, orc):
             assert res.stats["prim_tests"] == st["prim_tests"] and res.stats["rays"] == st["rays"]
 
 
+def test_very_high_sample_count_takes_the_exact_division_path(rt, orc):
+    """A unit of 16 pixels x 300 000 samples has more than 2^22 items: the sample -> pixel mapping falls back from the float
+    reciprocal (rt_device.h div_uniform) to integer division.  Few pixels, so the oracle still finishes in seconds."""
+    import dataclasses
+    objs, cam, w, h = scenes.all_materials(spp=300000, depth=6, pixels=1)
+    for passes in (1, 2):
+        rt.set_passes(passes)
+        try:
+            res = rt.Scene.make(objs).render_rows(w, h, cam, seed=23, counters=True)
+        finally:
+            rt.set_passes(0)
+        acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=23, threads=8)
+        assert np.array_equal(res.accum, acc) and res.stats["samples"] == st["samples"] and res.stats["rays"] == st["rays"]
+        assert res.accum[..., 0].max() == 300000
+
+
 def test_six_thousand_spheres_binned_tree_build(rt, orc):
     """Above 4096 leaves per node the surface-area build switches from a full sweep to 32 centroid bins (rt_scene.h): same bar."""
     objs, cam, w, h = scenes.many_spheres(n=6000, seed=4, spp=8, depth=6, pixels=8)
