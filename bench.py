@@ -43,8 +43,10 @@ def profiled_traffic():
     phys = None
     try:  # the physical reading of the same profile: what actually limits the kernel
         v = {k: float(x) for k, x in vals.items()}
-        waves_per_simd = v["SQ_WAVES"] / (256 * 4)
-        phys = {"valu_issue_busy_frac": round(v["SQ_ACTIVE_INST_VALU"] * waves_per_simd / v["SQ_WAVE_CYCLES"], 3),
+        # SQ_ACTIVE_INST_VALU is in quad-cycles summed over waves; GRBM_GUI_ACTIVE is cycles summed over the 8 XCDs; 1024 SIMDs
+        simd_cycles = 1024.0 * v["GRBM_GUI_ACTIVE"] / 8.0
+        phys = {"valu_issue_busy_frac": round(4.0 * v["SQ_ACTIVE_INST_VALU"] / simd_cycles, 3),
+                "resident_waves_per_simd": round(4.0 * v["SQ_WAVE_CYCLES"] / simd_cycles, 2),
                 "valu_lane_utilisation": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_INSTS_VALU"] * 64.0), 3),
                 "valu_wave_instructions": int(v["SQ_INSTS_VALU"]), "lds_wave_instructions": int(v["SQ_INSTS_LDS"])}
     except (KeyError, ZeroDivisionError):
