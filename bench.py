@@ -188,6 +188,20 @@ def main():
     # the counters of one launch (deterministic for a seed): an untimed replica with the counting kernel variant
     st = rtd.render_shard_device(scene, cam, w, h, args.seed, local_rank, first, stride, n, local, stream=stream.cuda_stream,
                                  counters=True, want_stats=True)
+    # the same launch over BoundingBoxTree.make's own tree: its box-test count is the reference's (and the oracle's); every other
+    # counter and every pixel must be the walked (surface-area) tree's -- checked here on the real workload, untimed
+    rt.set_walk_tree("reference")
+    try:
+        ref_scene = rt.Scene.make(objs)
+    finally:
+        rt.set_walk_tree("sah")
+    check = torch.zeros_like(local)
+    st_ref = rtd.render_shard_device(ref_scene, cam, w, h, args.seed, local_rank, first, stride, n, check, stream=stream.cuda_stream,
+                                     counters=True, want_stats=True)
+    torch.cuda.synchronize(dev)
+    if not torch.equal(check, local) or any(st_ref[k] != st[k] for k in ("rays", "prim_tests", "reflections", "samples", "pixels_early")):
+        raise SystemExit("walking the reference's tree and the surface-area tree gave different results")
+    del check, ref_scene
     step()  # untimed, whatever --warmup says: first launch of the timed kernel variant, stream-ordered pool set-up, and (N>1)
             # the first gather, which sets up RCCL's peer-to-peer connections over xGMI
     for _ in range(args.warmup):
@@ -207,7 +221,8 @@ def main():
     dt = time.perf_counter() - t0
 
     tot = torch.tensor([dt, float(st["rays"]), float(st["aabb_tests"]), float(st["prim_tests"]), float(st["reflections"]),
-                        float(st["samples"]), float(st["pixels_early"]), k_ms / max(1, args.steps)], dtype=torch.float64, device=dev)
+                        float(st["samples"]), float(st["pixels_early"]), k_ms / max(1, args.steps), float(st_ref["aabb_tests"])],
+                       dtype=torch.float64, device=dev)
     if world > 1:
         if args.backend == "gloo":
             tot = tot.cpu()
@@ -218,8 +233,10 @@ def main():
         dt = float(mx[0])
         job = {k: int(sm[i + 1]) for i, k in enumerate(("rays", "aabb_tests", "prim_tests", "reflections", "samples", "pixels_early"))}
         kernel_ms = float(mx[7])
+        job["aabb_tests_reference_tree"] = int(sm[8])
     else:
         job = {k: int(st[k]) for k in ("rays", "aabb_tests", "prim_tests", "reflections", "samples", "pixels_early")}
+        job["aabb_tests_reference_tree"] = int(st_ref["aabb_tests"])
         kernel_ms = float(tot[7])
 
     if rank == 0:
@@ -239,7 +256,9 @@ def main():
             "config": {"workload": f"{label}, seed {args.seed}), "
                                    f"maxW={w} maxH={h} -> {cols}x{rows} px, {cam.SamplesPerPixel} spp adaptive, {cam.BounceDepth} bounces",
                        "spheres_bounded": info["n_bounded"], "unbounded": info["n_unbounded"], "tree_nodes": info["n_nodes"],
-                       "lds_resident_scene": bool(info["lds_resident"]), "sharding": f"rows interleaved over {world} rank(s), one gather"},
+                       "lds_resident_scene": bool(info["lds_resident"]),
+                       "walk_tree": "surface-area build over the reference's leaf boxes (same hits; DESIGN.md 'Walk tree')" if info["walk_tree"] == 0
+                                    else "BoundingBoxTree.make's own", "sharding": f"rows interleaved over {world} rank(s), one gather"},
             "job": {**job, "pixels": rows * cols, "wall_s_per_frame": round(ms_per_step / 1e3, 4),
                     "ray_sphere_tests_per_s": round(job["prim_tests"] / (ms_per_step * 1e-3), 1),
                     "aabb_tests_per_s": round(job["aabb_tests"] / (ms_per_step * 1e-3), 1),
