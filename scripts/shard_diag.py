@@ -6,8 +6,8 @@ from ray_tracing_fsharp_amd import distributed as rtd
 objs, cam, w, h = rt.sample_images.config3_final()
 scene = rt.Scene.make(objs)
 rows, cols = 2*h+1, 2*w+1
-for world in (1, 8):
-    for chunk in (16, 4):
+for world in (1, 4, 8):
+    for chunk in (0,):
         rt.set_launch_config(0, chunk)
         first, stride, n = rtd.shard_rows(rows, 0, world)
         local = torch.zeros((n, cols, 4), dtype=torch.int32, device="cuda:0")
