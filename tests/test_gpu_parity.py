@@ -498,6 +498,21 @@ def test_very_high_sample_count_takes_the_exact_division_path(rt, orc):
         assert res.accum[..., 0].max() == 300000
 
 
+def test_order_of_bounded_objects_does_not_change_a_pixel(rt):
+    """Permuting the bounded spheres changes both trees (the reference's and the walked one) and the object ranks, not one sum."""
+    objs, cam, w, h = scenes.small_final(seed=11, spp=24, depth=30, pixels=20)
+    base = rt.Scene.make(objs).render_rows(w, h, cam, seed=4, counters=True)
+    rng = np.random.default_rng(8)
+    bounded = [i for i, o in enumerate(objs) if o.kind == 0]
+    for _ in range(4):
+        perm = list(range(len(objs)))
+        for dst, src in zip(bounded, rng.permutation(bounded)):
+            perm[dst] = int(src)
+        res = rt.Scene.make([objs[i] for i in perm]).render_rows(w, h, cam, seed=4, counters=True)
+        assert np.array_equal(res.accum, base.accum)
+        assert all(res.stats[k] == base.stats[k] for k in ("rays", "prim_tests", "reflections", "samples"))
+
+
 def test_six_thousand_spheres_binned_tree_build(rt, orc):
     """Above 4096 leaves per node the surface-area build switches from a full sweep to 32 centroid bins (rt_scene.h): same bar."""
     objs, cam, w, h = scenes.many_spheres(n=6000, seed=4, spp=8, depth=6, pixels=8)
