@@ -1,6 +1,7 @@
 """GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
 Bar: bit-exact (integer sums, bytes, indices, and every double the unit hooks return)."""
 import dataclasses
+import os
 
 import numpy as np
 import pytest
@@ -522,6 +523,30 @@ def test_six_thousand_spheres_binned_tree_build(rt, orc):
     acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=17, threads=8)
     assert np.array_equal(res.accum, acc) and np.array_equal(res.rgb, rgb)
     assert all(res.stats[k] == st[k] for k in ("rays", "prim_tests", "reflections", "samples")) and res.stats["aabb_tests"] < st["aabb_tests"]
+
+
+def _cpu_quota():
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    return os.cpu_count() or 1
+
+
+def test_full_size_config3_equals_the_oracle(rt, orc):
+    """The metric's own frame -- BASELINE config 3, 2401x1601 px, 500 spp, 50 bounces, 3.5e9 rays -- against the oracle, whole:
+    every one of the 3,844,001 PixelStats, and the ray / leaf-test / reflection / sample counts (the box-test count under the
+    reference's tree is pinned by test_full_size_config3_properties).  The oracle needs ~45 s on the GPU box's 16 CPUs."""
+    objs, cam, w, h = rt.sample_images.config3_final()
+    res = rt.Scene.make(objs).render_rows(w, h, cam, seed=2024, counters=True)
+    acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=2024, threads=min(32, _cpu_quota()))
+    assert np.array_equal(res.accum, acc)
+    assert np.array_equal(res.rgb, rgb)
+    for k in ("rays", "prim_tests", "reflections", "samples", "pixels", "pixels_early"):
+        assert res.stats[k] == st[k], k
+    assert st["aabb_tests"] == 98205213022 and st["rays"] == 3503018818
 
 
 def test_scene_larger_than_lds_uses_the_global_memory_kernel(rt, orc):
