@@ -273,6 +273,12 @@ def test_config2_three_lambert_reduced(rt, orc):
     _assert_render_equal(*_render_both(rt, orc, objs, cam, w, h, seed=2))
 
 
+def test_config2_full_size_equals_the_oracle(rt, orc):
+    """BASELINE config 2 whole (801x451 px, 100 spp, 50 bounces): every PixelStats and every counter."""
+    objs, cam, w, h = rt.sample_images.config2_three_lambert()
+    _assert_render_equal(*_render_both(rt, orc, objs, cam, w, h, seed=2024))
+
+
 def test_config3_final_scene_rows(rt, orc):
     """BASELINE config 3 at FULL geometry (2401x1601, 500 spp, depth 50): three image rows through sky, horizon, spheres."""
     objs, cam, w, h = rt.sample_images.config3_final()
@@ -607,6 +613,19 @@ def test_config5_full_geometry_row(rt, orc):
     differing = np.count_nonzero(np.any(res.accum != acc, axis=-1))
     assert differing <= 4, differing
     assert set(np.unique(res.accum[..., 0])) <= {11, 2000}
+
+
+def test_config5_whole_frame_at_100_spp(rt, orc):
+    """BASELINE config 5's scene and image size, whole frame, at 100 of its 2000 samples per pixel (the oracle then needs ~15 s):
+    earth-textured sphere, Dielectric sphere, mirror InfinitePlane, the 485 spheres.  Texture lookups go through acos/atan2
+    (OCML on the device, libm in the oracle), so a handful of pixels may differ by one flipped texel; everything else is exact."""
+    earth = scenes.golden("earthmap_rgb")["rgb"]
+    objs, cam, w, h = rt.sample_images.config5_mixed(earth, spp=100)
+    res = rt.Scene.make(objs).render_rows(w, h, cam, seed=5, counters=True)
+    acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=5, threads=min(32, _cpu_quota()))
+    differing = np.count_nonzero(np.any(res.accum != acc, axis=-1))
+    assert differing <= 8, differing
+    assert abs(res.stats["rays"] - st["rays"]) <= 200 * 8 and res.stats["pixels"] == st["pixels"] == (2 * w + 1) * (2 * h + 1)
 
 
 @pytest.mark.parametrize("chunk", [0, 1, 5, 64])
