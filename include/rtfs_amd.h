@@ -142,7 +142,8 @@ typedef struct rt_scene_info {
 } rt_scene_info;
 
 /* Scene.make (Scene.fs:15-28): partitions bounded/unbounded, builds the BoundingBoxTree on the host,
- * flattens it (DFS pre-order + skip links) and keeps a host copy; device copies are made lazily per device. */
+ * builds the tree the device walks over the same Leaf boxes (rt_set_walk_tree), flattens that (DFS pre-order, on-hit and
+ * on-miss successor per node) and keeps a host copy; device copies are made lazily per device. */
 int rt_scene_create(const rt_hittable *hittables, size_t n_hittables,
                     const rt_texture *textures, size_t n_textures, rt_scene **out);
 void rt_scene_destroy(rt_scene *scene);
