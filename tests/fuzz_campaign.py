@@ -1,0 +1,84 @@
+"""Long-running fuzz of the HIP path against the oracle (run by hand on a GPU box: `python tests/fuzz_campaign.py [n_scenes] [first_seed]`;
+the pytest suite runs a 40-scene slice of the same idea).  Scenes: 3-60 bounded spheres of every style, overlapping and nested, now and
+then exact duplicates (equal t^2: the tie rule), negative radii, unbounded spheres and planes, cameras anywhere, bounce depths from 0.
+Each scene is rendered with the surface-area walk tree and with the reference's own tree; both must equal the oracle bit for bit."""
+import dataclasses
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle as orc  # noqa: E402
+import scenes  # noqa: E402
+
+rt = scenes.rt
+P, V, S, PS, H, Px, Tex = scenes.P, scenes.V, scenes.S, scenes.PS, scenes.H, scenes.Px, scenes.Tex
+
+
+def scene(seed):
+    rng = np.random.default_rng(seed)
+    u = lambda a, b: float(rng.uniform(a, b))  # noqa: E731
+    col = lambda: Px(*(int(x) for x in rng.integers(0, 256, 3)))  # noqa: E731
+
+    def style():
+        k = int(rng.integers(0, 7))
+        return [S.LightSource(Tex(col())), S.LightSourceCap(col()), S.PureReflection(u(0, 1), Tex(col())), S.FuzzedReflection(u(0, 1), Tex(col()), u(0, 1)),
+                S.LambertReflection(u(0, 1), Tex(col())), S.Dielectric(u(0, 1), Tex(col()), u(0.7, 2.0), u(0, 1)), S.Glass(u(0.5, 1), Tex(col()), u(0.7, 2.0))][k]
+
+    objs = []
+    n = int(rng.integers(3, 61))
+    spread = u(1.0, 6.0)
+    for _ in range(n):
+        c, r = P(u(-spread, spread), u(-1, 2.5), u(0, 2 * spread)), u(0.05, 1.5) * (-1.0 if rng.random() < 0.08 else 1.0)
+        objs.append(H.Sphere(rt.Sphere.make(style(), c, r)))
+        if rng.random() < 0.1:  # an exact duplicate with another material: equal t^2
+            objs.append(H.Sphere(rt.Sphere.make(style(), c, r)))
+    for _ in range(int(rng.integers(0, 3))):
+        objs.append(H.UnboundedSphere(rt.Sphere.make(style(), P(u(-3, 3), u(-3, 3), u(0, 6)), u(0.5, 3.0))))
+    for _ in range(int(rng.integers(0, 3))):
+        st = [PS.LightSource(Tex(col())), PS.PureReflection(u(0, 1), col()), PS.LambertReflection(u(0, 1), col()), PS.FuzzedReflection(u(0, 1), col(), u(0, 1))][int(rng.integers(0, 4))]
+        objs.append(H.InfinitePlane(rt.InfinitePlane.make(st, P(u(-3, 3), u(-3, 3), u(-3, 6)), scenes.unit(*rng.normal(size=3)))))
+    if rng.random() < 0.8:
+        objs.append(H.UnboundedSphere(rt.Sphere.make(S.LightSource(Tex(col())), P(0.0, 0.0, 0.0), u(30.0, 400.0))))
+    order = rng.permutation(len(objs))
+    objs = [objs[i] for i in order]
+    cam = dataclasses.replace(rt.Camera.makeBasic(int(rng.integers(1, 40)), u(0.5, 3.0), u(0.8, 2.0), P(u(-2, 2), u(-0.5, 2.0), u(-4, 2)),
+                                                  scenes.unit(*rng.normal(size=3)), V(0.0, 1.0, 0.05)), BounceDepth=int(rng.integers(0, 30)))
+    return objs, cam, int(rng.integers(2, 13)), int(rng.integers(2, 9))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rays = 0
+    for i in range(first, first + n):
+        objs, cam, w, h = scene(i)
+        acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=i, threads=8)
+        for tree in ("sah", "reference"):
+            rt.set_walk_tree(tree)
+            try:
+                s = rt.Scene.make(objs)
+            finally:
+                rt.set_walk_tree("sah")
+            for passes in ((0, 2) if i % 5 == 0 else (0,)):
+                rt.set_passes(passes)
+                try:
+                    res = s.render_rows(w, h, cam, seed=i, counters=True)
+                finally:
+                    rt.set_passes(0)
+                bad = (not np.array_equal(res.accum, acc)) or any(res.stats[k] != st[k] for k in ("rays", "prim_tests", "reflections", "samples"))
+                if tree == "reference":
+                    bad = bad or res.stats["aabb_tests"] != st["aabb_tests"]
+                if bad:
+                    print(f"MISMATCH scene {i} tree {tree} passes {passes}: {np.count_nonzero(np.any(res.accum != acc, axis=-1))} pixels differ", flush=True)
+                    sys.exit(1)
+        rays += st["rays"]
+        if (i - first) % 100 == 99:
+            print(f"{i - first + 1} scenes ok, {rays} rays", flush=True)
+    print(f"fuzz campaign: {n} scenes from seed {first}, {rays} rays, both walk trees: all equal to the oracle", flush=True)
+
+
+if __name__ == "__main__":
+    main()
