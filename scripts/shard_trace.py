@@ -1,0 +1,16 @@
+"""A few renders of rank 0's 1/8 shard of the bench frame, for `rocprofv3 --kernel-trace`: durations of pass A, the list ordering, pass B
+and the gaps between them."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ray_tracing_fsharp_amd as rt
+from ray_tracing_fsharp_amd import distributed as rtd
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+objs, cam, w, h = rt.sample_images.config3_final()
+scene = rt.Scene.make(objs)
+rows, cols = 2 * h + 1, 2 * w + 1
+first, stride, n = rtd.shard_rows(rows, 0, world)
+local = torch.zeros((n, cols, 4), dtype=torch.int32, device="cuda:0")
+for _ in range(4):
+    st = rtd.render_shard_device(scene, cam, w, h, 2024, 0, first, stride, n, local, want_stats=True)
+    print(st["kernel_ms"], flush=True)
