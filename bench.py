@@ -269,7 +269,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src, "physical_from_same_profile": physical,
                          "kernel": "rtd::render_kernel", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": rank_bytes,
-                         "note": "algorithmic scene bytes (served from LDS); physical HBM traffic is in profiles/ and DESIGN.md"},
+                         "limited_by": "VALU issue (busy fraction below) at ~57 % lane occupancy; neither HBM nor MFMA (DESIGN.md section 4)",
+                         "note": "achieved = algorithmic scene bytes / kernel time; LDS serves them, hence frac > 1; `traffic` is the physical HBM byte count"},
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(objs, cam, w, h, args.seed, args.cpu_seconds)
