@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
@@ -146,6 +146,15 @@ typedef struct rt_scene_info {
  * on-miss successor per node) and keeps a host copy; device copies are made lazily per device. */
 int rt_scene_create(const rt_hittable *hittables, size_t n_hittables,
                     const rt_texture *textures, size_t n_textures, rt_scene **out);
+/* Per-scene settings, handed over at creation instead of through the process-wide rt_set_walk_tree default. */
+typedef struct rt_scene_options {
+    uint32_t struct_size; /* sizeof(rt_scene_options) as the caller compiled it (fields beyond it keep their defaults) */
+    int32_t  walk_tree;   /* RT_WALK_TREE_*; -1 = the process default (rt_set_walk_tree) */
+} rt_scene_options;
+/* rt_scene_create with explicit options (NULL = all defaults).  Thread-safe: reads no process-wide setting when every
+ * option is given. */
+int rt_scene_create_ex(const rt_hittable *hittables, size_t n_hittables, const rt_texture *textures, size_t n_textures,
+                       const rt_scene_options *options, rt_scene **out);
 void rt_scene_destroy(rt_scene *scene);
 int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
 /* Flattened tree for inspection/tests: skip[n_nodes], prim[n_nodes] (-1 for Branch), boxes[n_nodes*6] as
@@ -189,11 +198,55 @@ int rt_render(const rt_scene *scene, const rt_camera *camera,
 
 /* Same, with outputs left in device memory (d_accum / d_rgb are device pointers on `device`) and the launch
  * enqueued on `stream` (a hipStream_t, NULL = the null stream).  If `stats` is non-NULL the call synchronises
- * the stream and fills it; with stats == NULL it returns right after the launch. */
+ * the stream and fills it; with stats == NULL it returns right after the launch.  Any number of launches may be in flight:
+ * each takes its counters, work queue and camera from stream-ordered scratch of its own.  The caller's current HIP device
+ * is left as it was. */
 int rt_render_device(const rt_scene *scene, const rt_camera *camera,
                      int32_t max_width_coord, int32_t max_height_coord, uint64_t seed,
                      int32_t device, int32_t row_first, int32_t row_stride, int32_t n_rows,
                      uint32_t flags, void *d_accum, void *d_rgb, void *stream, rt_stats *stats);
+
+/* Launch settings of one render call.  0 in any field = that field's process default (the rt_set_* calls below, which
+ * exist for bench sweeps); a call that passes a fully specified struct reads no process-wide state.  No setting ever
+ * changes a result -- only which wave traces which sample when. */
+typedef struct rt_render_options {
+    uint32_t struct_size;   /* sizeof(rt_render_options) as the caller compiled it */
+    int32_t  block_threads; /* 256, 512, 768 or 1024 threads per workgroup */
+    int32_t  chunk_pixels;  /* pixels per wave work unit, <= 64 */
+    int32_t  blocks_per_cu; /* cap on resident workgroups per CU */
+    int32_t  yield_lanes;   /* lane-scheduling thresholds (DESIGN.md "Kernel") */
+    int32_t  refill_lanes;
+    int32_t  passes;        /* 1 fused kernel, 2 two passes (phase 1 + decision, cost-ordered phase 2); 0 = default (by shard size) */
+    int32_t  park_lanes;    /* capacity of a wave's pool of parked rare-style paths (<= 256); 0 = default, -1 = never park */
+} rt_render_options;
+int rt_render_device_ex(const rt_scene *scene, const rt_camera *camera,
+                        int32_t max_width_coord, int32_t max_height_coord, uint64_t seed,
+                        int32_t device, int32_t row_first, int32_t row_stride, int32_t n_rows,
+                        uint32_t flags, void *d_accum, void *d_rgb, void *stream,
+                        const rt_render_options *options, rt_stats *stats);
+
+/*
+ * Scene.render for a whole frame on SEVERAL GPUs of one node from ONE process (Scene.fs:196-236):
+ * device i of `devices[0..n_devices)` renders the image rows r = i, i + n_devices, ... (interleaved: adaptive sampling makes
+ * sky rows ~11/spp the cost of object rows) on a stream of its own, all devices concurrently; then ONE gather brings the
+ * per-device PixelStats buffers together and the frame is handed back de-interleaved in host memory:
+ * accum_host rows*cols*4 int32, rgb_host rows*cols*3 uint8 (may be NULL).  Streams are keyed by the global pixel index, so
+ * the frame is bit-identical for any device count.
+ *
+ * gather: RT_GATHER_RCCL   ncclGroupStart / ncclRecv x (n-1) on devices[0] / ncclSend on the others / ncclGroupEnd over
+ *                          xGMI (librccl.so is loaded on first use), then one strided device-to-host copy from devices[0];
+ *         RT_GATHER_PEER   hipMemcpyPeerAsync to devices[0] instead of RCCL (also works when `devices` repeats an id);
+ *         RT_GATHER_HOST   every device copies its own shard to the host over its own PCIe link (no device-side gather);
+ *         RT_GATHER_AUTO   RCCL when n_devices > 1, the ids are distinct and librccl.so loads; else PEER.
+ * stats (may be NULL): n_devices entries, one per device's shard; kernel_ms is that device's render time, total_ms the
+ * wall time of the whole call (the same in every entry).
+ */
+enum rt_gather { RT_GATHER_AUTO = 0, RT_GATHER_RCCL = 1, RT_GATHER_PEER = 2, RT_GATHER_HOST = 3 };
+int rt_render_frame(const rt_scene *scene, const rt_camera *camera,
+                    int32_t max_width_coord, int32_t max_height_coord, uint64_t seed,
+                    const int32_t *devices, int32_t n_devices, uint32_t flags, int32_t gather,
+                    const rt_render_options *options,
+                    int32_t *accum_host, uint8_t *rgb_host, rt_stats *stats);
 
 /* ---- Output side (ImageOutput.fs:11-30,163-197) -------------------------------------------------- */
 uint8_t rt_gamma_correct(uint8_t b); /* PixelOutput.correct (ImageOutput.fs:11-18) */
@@ -214,27 +267,39 @@ int64_t rt_parse_pixel_map(const uint8_t *data, size_t n, int32_t rows, int32_t 
 int rt_device_count(void);         /* 0 when no HIP device is visible (never an error) */
 const char *rt_last_error(void);   /* thread-local message of the last failing call */
 int rt_abi_version(void);
-/* sizeof of the ABI structs as compiled: 0 rt_hittable, 1 rt_texture, 2 rt_camera, 3 rt_scene_info, 4 rt_stats (bindings check their mirrors). */
+/* sizeof of the ABI structs as compiled: 0 rt_hittable, 1 rt_texture, 2 rt_camera, 3 rt_scene_info, 4 rt_stats,
+ * 5 rt_render_options, 6 rt_scene_options (bindings check their mirrors). */
 size_t rt_abi_sizeof(int which);
+/* Byte offset of field number `field` (declaration order, from 0) of struct `which` (numbering of rt_abi_sizeof), or
+ * (size_t)-1 past the last field: a binding in another language asserts its own layout against these at start-up
+ * (the F# StructLayout(Sequential) mirrors; ray-tracing-fsharp_amd/_lib.py: the ctypes ones). */
+size_t rt_abi_offsetof(int which, int field);
 /* Tunables of the render kernel: threads per workgroup (256, 512, 768 or 1024) and pixels per wave work unit (<= 64).
- * 0 keeps the default.  Process-wide; meant for bench sweeps. */
+ * 0 keeps the default.  Process-wide DEFAULTS for calls that pass no rt_render_options; meant for bench sweeps. */
 int rt_set_launch_config(int32_t block_threads, int32_t chunk_pixels, int32_t blocks_per_cu);
 /* Lane-scheduling thresholds of the render kernel (DESIGN.md "Kernel"): a stage yields once `yield_lanes` lanes wait for
  * another stage; idle lanes are refilled once `refill_lanes` are idle.  0 keeps the default.  Results never depend on them. */
 int rt_set_schedule(int32_t yield_lanes, int32_t refill_lanes);
 /* Which binary tree over the Leaf boxes the device walks, for scenes created AFTERWARDS.  RT_WALK_TREE_SAH (default): a
  * surface-area-heuristic build, ~14 % fewer box tests per ray on the reference's scenes; RT_WALK_TREE_REFERENCE:
- * BoundingBoxTree.make's own tree (BoundingBoxTree.fs:9-43), whose box-test count equals the reference's.  The hit a ray
- * returns -- hence every pixel -- is the same bit for bit under both (rt_scene.h "the tree the device WALKS"); only the
- * aabb_tests statistic differs. */
+ * BoundingBoxTree.make's own tree (BoundingBoxTree.fs:9-43) with Array.sortBy taken as a STABLE sort, i.e. the oracle's
+ * tree: the box-test count then equals the oracle's.  (.NET's Array.sortBy is an unstable introsort and every small sphere
+ * of the final scene ties on Min.y, so the real reference's tree -- and its count -- may differ from both.)  The hit a ray
+ * returns -- hence every pixel -- is the same bit for bit under every such tree (rt_scene.h "the tree the device WALKS");
+ * only the aabb_tests statistic differs. */
 int rt_set_walk_tree(int32_t kind);
 /* 1: always the fused kernel; 2: always two passes (phase 1 + decision, cost-ordered phase 2); 0: choose by shard size.
  * Results never depend on it. */
 int rt_set_passes(int32_t passes);
-/* Diagnostic: wave-level stage executions of this process' last render that had RT_RENDER_COUNTERS set:
- * {refill stages, node-loop trips, leaf stages, shade stages, lanes refilled, lanes shaded, sum of wave lifetimes and
- * first-start-to-last-end span (both in 100 MHz ticks), waves launched}. */
-int rt_last_stage_stats(uint64_t out[9]);
+/* Capacity of a wave's pool of parked paths: a path whose hit is neither an untextured light source nor an untextured
+ * Lambert sphere is set aside (88 bytes of state, in global memory) and shaded later together with others of its kind
+ * (DESIGN.md "Kernel").  0 = default (64), -1 = never park (such paths are shaded in their lane).  Results never depend on it. */
+int rt_set_park(int32_t park_lanes);
+/* Diagnostic: wave-level stage executions of the calling THREAD's last render that asked for stats with
+ * RT_RENDER_COUNTERS set: {refill stages, node-loop trips, leaf stages, shade stages, lanes refilled, lanes shaded, sum of
+ * wave lifetimes and first-start-to-last-end span (both in 100 MHz ticks), waves launched, general-reflection stages, lanes in them,
+ * lanes parked}. */
+int rt_last_stage_stats(uint64_t out[12]);
 
 /*
  * ---- Device unit hooks ---------------------------------------------------------------------------

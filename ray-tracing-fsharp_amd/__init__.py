@@ -31,6 +31,12 @@ def set_passes(passes: int = 0) -> None:
     check(lib.rt_set_passes(passes))
 
 
+def set_park(park_lanes: int = 0) -> None:
+    """Capacity of a wave's pool of parked rare-style paths: 0 default, -1 never park.  Never changes a result."""
+    from ._lib import check
+    check(lib.rt_set_park(park_lanes))
+
+
 def set_walk_tree(kind="sah") -> None:
     """Which tree over the Leaf boxes scenes created AFTERWARDS hand to the device: "sah" (default; fewer box tests per ray) or
     "reference" (BoundingBoxTree.make's own; its box-test count equals the reference's).  Pixels are identical under both."""

@@ -2,7 +2,7 @@
 tests/test_abi.py checks sizes against the values compiled into the library (rt_abi_sizeof)."""
 import ctypes as C
 
-RT_ABI_VERSION = 2
+RT_ABI_VERSION = 3
 
 RT_OK, RT_ERR_INVALID_ARGUMENT, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_IO = range(6)
 
@@ -19,6 +19,7 @@ RT_RAMP_CONST, RT_RAMP_U, RT_RAMP_V = range(3)
 RT_WALK_TREE_SAH, RT_WALK_TREE_REFERENCE = range(2)
 
 RT_RENDER_COUNTERS = 1
+RT_GATHER_AUTO, RT_GATHER_RCCL, RT_GATHER_PEER, RT_GATHER_HOST = range(4)
 
 D3 = C.c_double * 3
 
@@ -72,3 +73,24 @@ class rt_stats(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class rt_render_options(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("block_threads", C.c_int32), ("chunk_pixels", C.c_int32), ("blocks_per_cu", C.c_int32),
+        ("yield_lanes", C.c_int32), ("refill_lanes", C.c_int32), ("passes", C.c_int32), ("park_lanes", C.c_int32),
+    ]
+
+    def __init__(self, **kw):
+        super().__init__(struct_size=C.sizeof(rt_render_options), **kw)
+
+
+class rt_scene_options(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("walk_tree", C.c_int32)]
+
+    def __init__(self, walk_tree=-1):
+        super().__init__(struct_size=C.sizeof(rt_scene_options), walk_tree=walk_tree)
+
+
+# numbering of rt_abi_sizeof / rt_abi_offsetof
+ABI_STRUCTS = (rt_hittable, rt_texture, rt_camera, rt_scene_info, rt_stats, rt_render_options, rt_scene_options)

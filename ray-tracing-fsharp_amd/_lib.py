@@ -56,15 +56,18 @@ _dp, _u8p, _i32p, _u32p, _u64p = _P(C.c_double), _P(C.c_uint8), _P(C.c_int32), _
 SIGNATURES = {
     "rt_abi_version": (C.c_int, []),
     "rt_abi_sizeof": (C.c_size_t, [C.c_int]),
+    "rt_abi_offsetof": (C.c_size_t, [C.c_int, C.c_int]),
     "rt_last_error": (C.c_char_p, []),
     "rt_device_count": (C.c_int, []),
     "rt_set_launch_config": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "rt_set_schedule": (C.c_int, [C.c_int32, C.c_int32]),
     "rt_set_passes": (C.c_int, [C.c_int32]),
     "rt_set_walk_tree": (C.c_int, [C.c_int32]),
-    "rt_last_stage_stats": (C.c_int, [_u64p]),
+    "rt_set_park": (C.c_int, [C.c_int32]),
+    "rt_last_stage_stats": (C.c_int, [_u64p]),  # out[12]
     "rt_camera_make_basic": (C.c_int, [C.c_int32, C.c_double, C.c_double, _dp, _dp, _dp, _P(A.rt_camera)]),
     "rt_scene_create": (C.c_int, [_P(A.rt_hittable), C.c_size_t, _P(A.rt_texture), C.c_size_t, _P(C.c_void_p)]),
+    "rt_scene_create_ex": (C.c_int, [_P(A.rt_hittable), C.c_size_t, _P(A.rt_texture), C.c_size_t, _P(A.rt_scene_options), _P(C.c_void_p)]),
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_scene_get_info": (C.c_int, [C.c_void_p, _P(A.rt_scene_info)]),
     "rt_scene_get_tree": (C.c_int, [C.c_void_p, _i32p, _i32p, _dp]),
@@ -73,6 +76,11 @@ SIGNATURES = {
                             C.c_int32, C.c_uint32, _i32p, _u8p, _P(A.rt_stats)]),
     "rt_render_device": (C.c_int, [C.c_void_p, _P(A.rt_camera), C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, _P(A.rt_stats)]),
+    "rt_render_device_ex": (C.c_int, [C.c_void_p, _P(A.rt_camera), C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, _P(A.rt_render_options),
+                                      _P(A.rt_stats)]),
+    "rt_render_frame": (C.c_int, [C.c_void_p, _P(A.rt_camera), C.c_int32, C.c_int32, C.c_uint64, _i32p, C.c_int32, C.c_uint32, C.c_int32,
+                                  _P(A.rt_render_options), _i32p, _u8p, _P(A.rt_stats)]),
     "rt_gamma_correct": (C.c_uint8, [C.c_uint8]),
     "rt_write_ppm": (C.c_int, [C.c_char_p, _u8p, C.c_int32, C.c_int32, C.c_int32]),
     "rt_format_ppm": (C.c_int64, [_u8p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]),
@@ -103,8 +111,13 @@ def check(code):
         raise RtError(code, (lib.rt_last_error() or b"").decode("utf-8", "replace"))
 
 
-for _i, _t in enumerate((A.rt_hittable, A.rt_texture, A.rt_camera, A.rt_scene_info, A.rt_stats)):
+for _i, _t in enumerate(A.ABI_STRUCTS):  # sizes and every field offset of the ctypes mirrors against the library as compiled
     if lib.rt_abi_sizeof(_i) != C.sizeof(_t):
         raise ImportError(f"ABI mismatch for {_t.__name__}: library {lib.rt_abi_sizeof(_i)} vs ctypes {C.sizeof(_t)}")
+    for _k, (_fname, *_rest) in enumerate(_t._fields_):
+        if lib.rt_abi_offsetof(_i, _k) != getattr(_t, _fname).offset:
+            raise ImportError(f"ABI mismatch for {_t.__name__}.{_fname}: library offset {lib.rt_abi_offsetof(_i, _k)} vs ctypes {getattr(_t, _fname).offset}")
+    if lib.rt_abi_offsetof(_i, len(_t._fields_)) != C.c_size_t(-1).value:
+        raise ImportError(f"ABI mismatch for {_t.__name__}: the library has more fields than the ctypes mirror")
 if lib.rt_abi_version() != A.RT_ABI_VERSION:
     raise ImportError("ABI version mismatch between librtfs_amd.so and _abi.py")

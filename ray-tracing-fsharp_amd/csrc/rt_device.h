@@ -603,6 +603,40 @@ RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, 
     return false;
 }
 
+// The two cases that make up ~85 % of all path vertices of the reference's scenes, as a function of their own: a light
+// source without a parameterised texture (Sphere.fs:185-189, InfinitePlane.fs:52-56) and an untextured LambertReflection
+// sphere (Sphere.fs:162-182, 202-222).  Statement for statement what `reflection` executes for those objects -- the render
+// kernel shades them where they fall and hands every other style to `reflection` in batches (rt_render_kernel.h).
+// `fast_style` says which objects qualify (from the meta word alone).
+RTD_INLINE bool fast_style(i2 m) {
+    const uint32_t ks = (uint32_t) m.x & 31u; // kind | style << 2
+    return (((uint32_t) m.y) >> 24) == 0u && (ks == (RTD_KIND_SPHERE | (0u << 2)) || ks == (RTD_KIND_SPHERE | (4u << 2)) || ks == (RTD_KIND_PLANE | (0u << 2)));
+}
+template <bool LDS>
+RTD_INLINE bool reflection_fast(const SceneView<LDS> &sc, int obj, i2 m, V3 strike, V3 &o, V3 &d, uint32_t &colour, Rng &rng) {
+    const uint32_t texColour = (uint32_t) m.y & 0x00FFFFFFu;
+    if ((((uint32_t) m.x >> 2) & 7u) == 0u) { colour = pix_combine(colour, texColour); return true; } // LightSource, sphere or plane
+    const d2 g0 = sc.geo[obj * 3 + 0], g1 = sc.geo[obj * 3 + 1];
+    const double albedo = sc.mat[obj * 4 + 0];
+    const V3 c = mk(g0.x, g0.y, g1.x);
+    const double r2 = g1.y;
+    const bool flipped = (m.x >> 5) & 1;
+    V3 n;
+    if (!unitise(vsub(strike, c), n)) n = mk(0.0, 0.0, 0.0); // Sphere.normal (Sphere.fs:65-66)
+    V3 co = vsub(c, o);
+    int cmp = fcmp(dot(co, co), r2); // Sphere.fs:165-179
+    if ((cmp != CMP_GT) != flipped) n = vscale(-1.0, n);
+    colour = pix_darken(albedo, pix_combine(colour, texColour)); // Sphere.fs:203-207
+    const V3 centre = walk(strike, n, 1.0);                       // Sphere.fs:211-220
+    for (;;) {
+        V3 offset = random_unit(rng);
+        V3 target = walk(centre, offset, 1.0);
+        V3 nd;
+        if (unitise(vsub(target, strike), nd)) { o = strike; d = nd; break; }
+    }
+    return false;
+}
+
 // ---- Scene.traceOnce's ray construction (Scene.fs:129-144) ---------------------------------------------------------
 struct CameraParams {
     double eye[3], xo[3], xd[3], yd[3];

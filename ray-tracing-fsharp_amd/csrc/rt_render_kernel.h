@@ -21,6 +21,8 @@
 namespace rtd {
 
 #define RTD_MAX_CHUNK 64
+#define RTD_MAX_PARK 256
+#define RTD_PARK_DEFAULT 64
 
 struct RenderParams {
     const CameraParams *cam_ptr;   // device copy of the camera: read where a camera ray is built, not held in SGPRs
@@ -37,13 +39,16 @@ struct RenderParams {
     int32_t n_rows;
     int32_t k;                     // firstTrial = min 5 (spp/2)   (Scene.fs:172)
     int32_t chunk;                 // pixels per work unit, <= 64
-    int32_t yield_lanes;           // see run_items: a stage yields once this many lanes wait for another stage
-    int32_t refill_lanes;          // see run_items: idle lanes are refilled once this many are idle
+    int32_t yield_lanes;           // see Sched: a stage yields once this many lanes wait for another stage
+    int32_t refill_lanes;          // see Sched: idle lanes are refilled once this many are idle
+    int32_t park;                  // entries of a wave's park pool (0: rare styles are shaded in place)
     int32_t *accum;                // [n_rows*cols][4]
     uint8_t *rgb;                  // [n_rows*cols][3] or null
     unsigned long long *counters;  // [16]: rays, aabb, prim, refl, samples, pixels_early, -, -, then stage executions (COUNT):
                                    //       [8] refill [9] node trips [10] leaf stages [11] shade stages [12] lanes refilled [13] lanes shaded
+                                   //       and, 160 bytes in, [0] slow stages [1] lanes in them [2] lanes parked
     unsigned int *queue;           // work-unit counter of the fused kernel / of pass A, zeroed before launch
+    unsigned char *park_pool;      // [waves of the grid][RTD_PARK_ENTRY_BYTES * park]: per-wave pools of parked paths (see Sched)
     // two-pass rendering (see render_kernel): pass A appends (cost << 32 | local pixel) for every pixel that continues;
     // pass B walks `live_list` (those pixels ordered by decreasing cost) with its own queue
     unsigned long long *pairs;
@@ -69,6 +74,9 @@ RTD_INLINE uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor((unsigned long long) v, off, 64);
     return v;
+}
+RTD_INLINE uint32_t lane_rank(unsigned long long mask) { // number of set bits of `mask` below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
 }
 
 template <bool LDS> RTD_INLINE SceneView<LDS> make_view(const RenderParams &p, const unsigned char *lds_base);
@@ -97,136 +105,261 @@ template <> RTD_INLINE SceneView<false> make_view<false>(const RenderParams &p, 
     return v;
 }
 
-// Scheduling thresholds of run_items (lanes of a wave):
-//   yield_lanes  the node loop yields once this many lanes are waiting for another stage (a pending leaf test, or a finished
-//              walk that wants shading); the shade stage runs once this many walks are finished (or none is left walking)
-//   refill_lanes idle lanes are given new (pixel, sample) items once this many are idle (or nothing else is runnable)
-struct StageStats { uint32_t refill, trips, leaf, shade, refillLanes, shadeLanes; }; // wave-uniform, COUNT variant only
+struct StageStats { uint32_t refill, trips, leaf, shade, refillLanes, shadeLanes, slow, slowLanes, parkedLanes; }; // wave-uniform, COUNT variant only
 
 #define RTD_YIELD_DEFAULT 44
 #define RTD_REFILL_DEFAULT 12
 
+// ---- the lane scheduler shared by every render mode ------------------------------------------------------------------------
+// Every lane of a wave is a path slot in one of four states: IDLE (wants a new item), WALK (somewhere in the tree walk of its
+// current ray; the walk state survives while the lane is parked), DONE (tree exhausted: wants the unbounded-object tests and
+// Hittable.Reflection), SLOW (its hit needs the general `reflection`: any style but an untextured light source or Lambert sphere).
+// Per-ray work is heavy-tailed (tree nodes per ray: mean 24, p99 60, max 150), so running each stage until its slowest lane
+// finishes leaves ~70 % of the lanes idle.  Instead a stage runs while enough lanes want it:
+//   yield_lanes  the node loop yields once this many lanes are waiting for another stage (a pending leaf test, or a finished
+//                walk that wants shading); the shade stage runs once this many walks are finished (or none is left walking)
+//   refill_lanes idle lanes are given new work once this many are idle (or nothing else is runnable)
+// The shade stage shades the two common cases where they fall (reflection_fast) -- about 250 instructions.  The other styles'
+// code is twice as long and used to run in almost every shade stage for the two or three lanes that needed it; now such a
+// path is PARKED: its state (88 bytes) goes to the wave's own pool in global memory (L2-resident: a few KB per wave in use)
+// and the lane is free for other work.  When a refill finds at least as many parked paths as idle lanes (or no new items),
+// the idle lanes take parked paths instead of new items and run the general `reflection` together.  A pool that is full
+// (or switched off, p.park = 0) leaves the path in its lane and the general code runs for it at the next turn of the loop.
+// Which lane computes what when has no effect on any result: streams are per item.
+#define RTD_PARK_ENTRY_BYTES 96 /* 5 x 16 B + 8 B, padded */
+enum { L_IDLE = 0, L_WALK = 1, L_DONE = 2, L_SLOW = 3 };
+
+template <bool LDS, bool COUNT>
+struct Sched {
+    const RenderParams &p;
+    const SceneView<LDS> &sc;
+    Counters &cnt;
+    StageStats &ss;
+    unsigned char *pool; // this wave's park pool
+    uint32_t parked;     // wave-uniform
+    const int end;
+    // lane state
+    int st;
+    V3 o, d;
+    Walk w;
+    Rng rng;
+    uint32_t colour, slotOff;
+    int bounces;
+    // set by the stages for the caller's bookkeeping: this lane's path ended during the current turn, with this colour
+    bool ended;
+    uint32_t result;
+
+    RTD_INLINE Sched(const RenderParams &p_, const SceneView<LDS> &sc_, Counters &cnt_, StageStats &ss_, unsigned char *pool_)
+        : p(p_), sc(sc_), cnt(cnt_), ss(ss_), pool(pool_), parked(0u), end(sc_.end) {
+        st = L_IDLE;
+        o = mk(0, 0, 0); d = mk(0, 0, 0);
+        walk_begin(w, sc.first); w.off = end; // idle lanes are parked at `end`
+        rng.x = rng.y = rng.z = rng.w = 0;
+        colour = 0; slotOff = 0; bounces = 0;
+        ended = false; result = 0;
+    }
+
+    // a new (pixel, sample) item: Scene.traceOnce's ray (Scene.fs:129-150)
+    RTD_INLINE bool start_item(uint64_t pkey, uint32_t sample, int row, int col, uint32_t slot_off) {
+        rng = stream_for(pkey, sample);
+        slotOff = slot_off;
+        colour = RTD_WHITE;
+        bounces = 0;
+        const CameraParams *cp = p.cam_ptr;
+        asm volatile("" : "+s"(cp)); // keep the camera's 32 dwords out of the loop-carried SGPR set
+        if (camera_ray(*cp, row, col, rng, o, d)) {
+            st = L_WALK;
+            walk_begin(w, sc.first);
+            if (COUNT) cnt.rays++;
+            return true;
+        }
+        return false; // Scene.fs:144's ValueOption.get would throw; the sample counts as Black (adds nothing)
+    }
+
+    // ---- park pool: entry e of field f sits at pool + (f * park + e) * 16 (fields 0-4) / pool + 80 * park + e * 8 (field 5) ----
+    RTD_INLINE void park_store(uint32_t e) {
+        d2 *f = (d2 *) pool;
+        const uint32_t K = (uint32_t) p.park;
+        d2 v;
+        v.x = o.x; v.y = o.y; f[e] = v;
+        v.x = o.z; v.y = d.x; f[K + e] = v;
+        v.x = d.y; v.y = d.z; f[2u * K + e] = v;
+        i4 r; r.x = __double2loint(w.bestLen); r.y = __double2hiint(w.bestLen); r.z = (int) colour; r.w = (int) slotOff;
+        ((i4 *) pool)[3u * K + e] = r;
+        r.x = (int) rng.x; r.y = (int) rng.y; r.z = (int) rng.z; r.w = (int) rng.w;
+        ((i4 *) pool)[4u * K + e] = r;
+        i2 b; b.x = bounces; b.y = w.best;
+        ((i2 *) (pool + 80u * K))[e] = b;
+    }
+    RTD_INLINE void park_load(uint32_t e) {
+        const d2 *f = (const d2 *) pool;
+        const uint32_t K = (uint32_t) p.park;
+        const d2 a = f[e], b = f[K + e], c = f[2u * K + e];
+        const i4 t = ((const i4 *) pool)[3u * K + e], r = ((const i4 *) pool)[4u * K + e];
+        const i2 bo = ((const i2 *) (pool + 80u * K))[e];
+        o = mk(a.x, a.y, b.x); d = mk(b.y, c.x, c.y);
+        w.bestLen = __hiloint2double(t.y, t.x); colour = (uint32_t) t.z; slotOff = (uint32_t) t.w;
+        rng.x = (uint32_t) r.x; rng.y = (uint32_t) r.y; rng.z = (uint32_t) r.z; rng.w = (uint32_t) r.w;
+        bounces = bo.x; w.best = bo.y;
+        w.off = end;
+        st = L_SLOW;
+    }
+    // How many of `nIdle` idle lanes take parked paths now (wave-uniform): all of them once the pool holds that many, and
+    // whatever is left when there are no new items.
+    RTD_INLINE uint32_t unpark_count(uint32_t nIdle, bool haveNew) const {
+        if (parked == 0u) return 0u;
+        if (parked >= nIdle) return nIdle;
+        return haveNew ? 0u : parked;
+    }
+
+    // what follows Hittable.Reflection in Scene.traceRay (Scene.fs:105-112)
+    RTD_INLINE void after_reflection(bool absorbed) {
+        bool done = absorbed;
+        uint32_t res = colour;
+        if (!absorbed) {
+            bounces = bounces + 1;
+            if (bounces > p.depth) { done = true; res = RTD_HOTPINK; } // Scene.fs:98,114
+        }
+        if (done) { ended = true; result = res; st = L_IDLE; w.off = end; }
+        else {
+            st = L_WALK;
+            walk_begin(w, sc.first);
+            if (COUNT) cnt.rays++;
+        }
+    }
+
+    // ---- slow: the general Hittable.Reflection for the lanes whose hit is not one of the two common cases ----
+    RTD_INLINE void stage_slow() {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(st == L_SLOW);
+        if (m == 0ull) return;
+        if (COUNT) { ss.slow++; ss.slowLanes += (uint32_t) __popcll(m); }
+        if (st == L_SLOW) {
+            const V3 strike = walk(o, d, w.bestLen); // Ray.walkAlong ray bestLength (Scene.fs:91)
+            after_reflection(reflection<LDS>(sc, w.best, strike, o, d, colour, rng));
+        }
+    }
+
+    // ---- walk: BoundingBox.hits over the tree image, leaf tests deferred out of the node loop ----
+    // A lane steps iff w.off < end: finished walks sit at >= end, pending leaves carry RTD_LEAF (> end), idle lanes are
+    // parked at `end`.  So one compare gives the active set, and waiting = busy - active.
+    RTD_INLINE void stage_walk() {
+        if (__builtin_amdgcn_ballot_w64(st == L_WALK) == 0ull) return;
+        const int nBusy = __popcll(__builtin_amdgcn_ballot_w64(st != L_IDLE));
+        WalkCtx c = walk_ctx(d, w); // cheap to re-derive; keeps 9 doubles out of the parked state
+        const int stop = (nBusy - p.yield_lanes) > 0 ? (nBusy - p.yield_lanes) : 0; // active <= stop  <=>  waiting >= yield
+        for (;;) {
+            for (;;) {
+                const bool act = w.off < end;
+                const int nAct = __popcll(__builtin_amdgcn_ballot_w64(act));
+                if (nAct <= stop) break;
+                if (COUNT) ss.trips++;
+                if (act) {
+                    if (COUNT) cnt.aabb++;
+                    node_step<LDS>(sc, o, c, w);
+                }
+            }
+            if (COUNT && __builtin_amdgcn_ballot_w64((w.off & RTD_LEAF) != 0) != 0ull) ss.leaf++;
+            if (w.off & RTD_LEAF) {
+                if (COUNT) cnt.prim++;
+                leaf_test<LDS>(sc, o, d, c, w);
+            }
+            const bool fin = (st == L_WALK) && (w.off >= end);
+            if (fin) st = L_DONE;
+            const int nWalk = __popcll(__builtin_amdgcn_ballot_w64(st == L_WALK));
+            const int nDone = __popcll(__builtin_amdgcn_ballot_w64(st == L_DONE));
+            if (nWalk == 0 || nDone >= p.yield_lanes) break;
+        }
+    }
+
+    // ---- shade: the rest of Scene.hitObject (Scene.fs:77-91), then Hittable.Reflection for the common cases; the others park ----
+    RTD_INLINE void stage_shade() {
+        const unsigned long long dm = __builtin_amdgcn_ballot_w64(st == L_DONE);
+        if (dm == 0ull) return;
+        if (COUNT) { ss.shade++; ss.shadeLanes += (uint32_t) __popcll(dm); }
+        if (st == L_DONE) {
+            unbounded_tests<LDS, COUNT>(sc, o, d, w, cnt);
+            if (w.best < 0) { ended = true; result = RTD_BLACK; st = L_IDLE; w.off = end; } // "never heard from again": Black (Scene.fs:102-104)
+            else {
+                if (COUNT) cnt.refl++;
+                const i2 m = sc.meta[w.best];
+                if (fast_style(m)) {
+                    const V3 strike = walk(o, d, w.bestLen); // Ray.walkAlong ray bestLength (Scene.fs:91)
+                    after_reflection(reflection_fast<LDS>(sc, w.best, m, strike, o, d, colour, rng));
+                } else st = L_SLOW;
+            }
+        }
+        if (p.park > 0) {
+            const unsigned long long sm = __builtin_amdgcn_ballot_w64(st == L_SLOW);
+            if (sm != 0ull) {
+                const uint32_t room = (uint32_t) p.park - parked, want = (uint32_t) __popcll(sm);
+                const uint32_t rank = lane_rank(sm);
+                if (st == L_SLOW && rank < room) { park_store(parked + rank); st = L_IDLE; w.off = end; }
+                const uint32_t n = want < room ? want : room;
+                parked += n;
+                if (COUNT) ss.parkedLanes += n;
+            }
+        }
+    }
+
+    // PixelStats.add (Pixel.fs:97-101) for a lane whose path ended this turn; Count is implied by the item count
+    RTD_INLINE void add_result(RTD_AS3 uint32_t *acc3) const {
+        if (result != 0u) {
+            lds_add(acc3 + 0, result & 0xFFu);
+            lds_add(acc3 + 1, (result >> 8) & 0xFFu);
+            lds_add(acc3 + 2, (result >> 16) & 0xFFu);
+        }
+    }
+};
+
 // Trace `total` items of the current unit.  Item i belongs to pixel slot map[i / per] (or i / per when map is null)
 // and is sample s_base + i % per of that pixel; its colour is added to accumulator slot (sample < split ? 0 : 1).
-//
-// Every lane is a path slot in one of three states: IDLE (wants a new item), WALK (somewhere in the tree walk of its
-// current ray; the walk state survives while the lane is parked), DONE (tree exhausted: wants the unbounded-object tests
-// and Hittable.Reflection).  Per-ray work is heavy-tailed (tree nodes per ray: mean 26, p99 60, max 150), so running
-// each stage until its slowest lane finishes leaves ~70 % of the lanes idle.  Instead a stage runs while enough lanes
-// want it and yields to the stage that has collected the most waiting lanes; a ray with a long walk simply stays in WALK
-// across several rounds.  Which lane computes what when has no effect on any result (streams are per item).
 template <bool LDS, bool COUNT, bool COST>
-RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_AS3 uint32_t *acc, const RTD_AS3 uint32_t *pix,
+RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsigned char *pool, RTD_AS3 uint32_t *acc, const RTD_AS3 uint32_t *pix,
                           const RTD_AS3 uint32_t *live, bool use_live, uint32_t total, uint32_t per, uint32_t s_base,
                           uint32_t split, Counters &cnt, StageStats &ss) {
-    enum { IDLE = 0, WALK = 1, DONE = 2 };
-    int st = IDLE;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
-    const int end = sc.end;
-    Walk w; walk_begin(w, sc.first); w.off = end; // idle lanes are parked at `end`
-    Rng rng; rng.x = rng.y = rng.z = rng.w = 0;
-    uint32_t colour = 0, slotOff = 0;
-    int bounces = 0;
+    Sched<LDS, COUNT> L(p, sc, cnt, ss, pool);
     uint32_t next = 0; // wave-uniform
     const bool fastDiv = total < (1u << 22) && per < (1u << 23); // see div_uniform
     const float perRcp = 1.0f / (float) per;
     for (;;) {
-        // ---- refill: idle lanes take the next items of the unit (Scene.traceOnce's ray, Scene.fs:129-150) ----
-        const unsigned long long idle = __builtin_amdgcn_ballot_w64(st == IDLE);
-        const unsigned long long busy = ~idle;
-        if (idle != 0ull && next < total && (__popcll(idle) >= p.refill_lanes || busy == 0ull)) {
-            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
-            uint32_t item = next + rank;
-            if (COUNT) { ss.refill++; ss.refillLanes += (uint32_t) __popcll(idle); }
-            if (st == IDLE && item < total) {
-                uint32_t j = fastDiv ? div_uniform(item, per, perRcp) : item / per;
-                uint32_t s = s_base + (item - j * per);
-                uint32_t slot = use_live ? live[j] : j;
-                int row = (int) pix[slot * 4 + 0], col = (int) pix[slot * 4 + 1];
-                uint64_t pkey = (uint64_t) pix[slot * 4 + 2] | ((uint64_t) pix[slot * 4 + 3] << 32);
-                rng = stream_for(pkey, s);
-                slotOff = (((s < split) ? 0u : (uint32_t) p.chunk * 3u) + slot * 3u) | (slot << 16); // low half: acc word, high half: pixel slot
-                colour = RTD_WHITE;
-                bounces = 0;
-                const CameraParams *cp = p.cam_ptr;
-                asm volatile("" : "+s"(cp)); // keep the camera's 32 dwords out of the loop-carried SGPR set
-                if (camera_ray(*cp, row, col, rng, o, d)) {
-                    st = WALK;
-                    walk_begin(w, sc.first);
-                    if (COUNT) cnt.rays++;
-                }
-                // else: Scene.fs:144's ValueOption.get would throw; the sample counts as Black (adds nothing)
-            }
-            next += (uint32_t) __popcll(idle);
-            next = __builtin_amdgcn_readfirstlane(next);
-        }
-        if (__builtin_amdgcn_ballot_w64(st != IDLE) == 0ull) {
-            if (next >= total) break;
-            continue;
-        }
-
-        // ---- walk: BoundingBox.hits over the tree image, leaf tests deferred out of the node loop ----
-        // A lane steps iff w.off < end: finished walks sit at >= end, pending leaves carry RTD_LEAF (> end), idle lanes are
-        // parked at `end`.  So one compare gives the active set, and waiting = busy - active.
-        const int nBusy = __popcll(__builtin_amdgcn_ballot_w64(st != IDLE));
-        if (__builtin_amdgcn_ballot_w64(st == WALK) != 0ull) {
-            WalkCtx c = walk_ctx(d, w); // cheap to re-derive; keeps 9 doubles out of the parked state
-            const int stop = (nBusy - p.yield_lanes) > 0 ? (nBusy - p.yield_lanes) : 0; // active <= stop  <=>  waiting >= yield
-            for (;;) {
-                for (;;) {
-                    const bool act = w.off < end;
-                    const int nAct = __popcll(__builtin_amdgcn_ballot_w64(act));
-                    if (nAct <= stop) break;
-                    if (COUNT) ss.trips++;
-                    if (act) {
-                        if (COUNT) cnt.aabb++;
-                        node_step<LDS>(sc, o, c, w);
+        L.ended = false;
+        // ---- refill: idle lanes take parked paths or the next items of the unit ----
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(L.st == L_IDLE);
+        const bool haveNew = next < total;
+        if (idle != 0ull && (haveNew || L.parked != 0u) && (__popcll(idle) >= p.refill_lanes || ~idle == 0ull)) {
+            const uint32_t nIdle = (uint32_t) __popcll(idle);
+            const uint32_t rank = lane_rank(idle);
+            const uint32_t nUn = L.unpark_count(nIdle, haveNew);
+            if (COUNT) { ss.refill++; ss.refillLanes += nIdle; }
+            if (L.st == L_IDLE) {
+                if (rank < nUn) L.park_load(L.parked - 1u - rank);
+                else {
+                    const uint32_t item = next + (rank - nUn);
+                    if (item < total) {
+                        uint32_t j = fastDiv ? div_uniform(item, per, perRcp) : item / per;
+                        uint32_t s = s_base + (item - j * per);
+                        uint32_t slot = use_live ? live[j] : j;
+                        int row = (int) pix[slot * 4 + 0], col = (int) pix[slot * 4 + 1];
+                        uint64_t pkey = (uint64_t) pix[slot * 4 + 2] | ((uint64_t) pix[slot * 4 + 3] << 32);
+                        // low half: acc word, high half: pixel slot
+                        L.start_item(pkey, s, row, col, (((s < split) ? 0u : (uint32_t) p.chunk * 3u) + slot * 3u) | (slot << 16));
                     }
                 }
-                if (COUNT && __builtin_amdgcn_ballot_w64((w.off & RTD_LEAF) != 0) != 0ull) ss.leaf++;
-                if (w.off & RTD_LEAF) {
-                    if (COUNT) cnt.prim++;
-                    leaf_test<LDS>(sc, o, d, c, w);
-                }
-                const bool fin = (st == WALK) && (w.off >= end);
-                if (fin) st = DONE;
-                const int nWalk = __popcll(__builtin_amdgcn_ballot_w64(st == WALK));
-                const int nDone = __popcll(__builtin_amdgcn_ballot_w64(st == DONE));
-                if (nWalk == 0 || nDone >= p.yield_lanes) break;
             }
+            L.parked -= nUn;
+            next += nIdle - nUn;
+            next = __builtin_amdgcn_readfirstlane(next);
         }
-
-        // ---- finish: the rest of Scene.hitObject, then Hittable.Reflection (Scene.fs:77-112) ----
-        if (COUNT) { const unsigned long long dm = __builtin_amdgcn_ballot_w64(st == DONE); if (dm) { ss.shade++; ss.shadeLanes += (uint32_t) __popcll(dm); } }
-        if (st == DONE) {
-            unbounded_tests<LDS, COUNT>(sc, o, d, w, cnt);
-            bool done = false;
-            uint32_t result = RTD_BLACK;
-            if (w.best < 0) done = true; // "never heard from again": Black
-            else {
-                V3 strike = walk(o, d, w.bestLen); // Ray.walkAlong ray bestLength (Scene.fs:91)
-                if (COUNT) cnt.refl++;
-                if (reflection<LDS>(sc, w.best, strike, o, d, colour, rng)) { done = true; result = colour; }
-                else {
-                    bounces = bounces + 1;
-                    if (bounces > p.depth) { done = true; result = RTD_HOTPINK; } // Scene.fs:98,114
-                }
-            }
-            if (done) {
-                const uint32_t aoff = slotOff & 0xFFFFu;
-                if (result != 0u) { // PixelStats.add (Pixel.fs:97-101); Count is implied by the item count
-                    lds_add(acc + aoff + 0, result & 0xFFu);
-                    lds_add(acc + aoff + 1, (result >> 8) & 0xFFu);
-                    lds_add(acc + aoff + 2, (result >> 16) & 0xFFu);
-                }
-                if (COST) lds_add(acc + 11u * (uint32_t) p.chunk + (slotOff >> 16), (uint32_t) bounces + 1u); // Scene.hitObject calls of this path
-                st = IDLE;
-                w.off = end;
-            } else {
-                st = WALK;
-                walk_begin(w, sc.first);
-                if (COUNT) cnt.rays++;
-            }
+        if (__builtin_amdgcn_ballot_w64(L.st != L_IDLE) == 0ull) {
+            if (next >= total && L.parked == 0u) break;
+            continue;
+        }
+        L.stage_slow();
+        L.stage_walk();
+        L.stage_shade();
+        if (L.ended) {
+            L.add_result(acc + (L.slotOff & 0xFFFFu));
+            if (COST) lds_add(acc + 11u * (uint32_t) p.chunk + (L.slotOff >> 16), (uint32_t) L.bounces + 1u); // ~ Scene.hitObject calls of this path
         }
     }
 }
@@ -235,22 +368,15 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, RTD_A
 // hands out its npx*n2 items, and while the last paths of that range are still in flight it already reserves the next range and
 // hands out its items: two accumulator slots alternate, a range is flushed (its sums added to what pass A left in `accum`) when
 // its last path has ended.  There is no dependency between ranges, so no lane waits at a range boundary -- which is what makes
-// small ranges (good load balance across waves) affordable.  Lane states and stage scheduling are those of run_items.
+// small ranges (good load balance across waves) affordable.  Lane states and stage scheduling are Sched's.
 template <bool LDS, bool COUNT>
-RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, RTD_AS3 uint32_t *wv, uint32_t n1, uint32_t n2, Counters &cnt,
+RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsigned char *pool, RTD_AS3 uint32_t *wv, uint32_t n1, uint32_t n2, Counters &cnt,
                            StageStats &ss, uint64_t &sampleCount) {
     const int lane = threadIdx.x & 63;
     const uint32_t P = (uint32_t) p.chunk;
     const uint32_t SW = 7u * P; // words per slot: acc [P][3] then pix [P][4]
     const unsigned long long nList = (unsigned long long) *p.live_count;
-    enum { IDLE = 0, WALK = 1, DONE = 2 };
-    int st = IDLE;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
-    const int end = sc.end;
-    Walk w; walk_begin(w, sc.first); w.off = end;
-    Rng rng; rng.x = rng.y = rng.z = rng.w = 0;
-    uint32_t colour = 0, slotOff = 0; // word offset from wv of the path's accumulator triple (>= SW: slot 1)
-    int bounces = 0;
+    Sched<LDS, COUNT> L(p, sc, cnt, ss, pool); // slotOff: word offset from wv of the path's accumulator triple (>= SW: slot 1)
 
     // wave-uniform: the range being handed out (cur) and the one draining (prev)
     unsigned long long curFirst = 0, prevFirst = 0;
@@ -282,6 +408,7 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, RTD_
     };
 
     for (;;) {
+        L.ended = false;
         // ---- ranges: flush what has drained, reserve the next one when the current one has no items left ----
         if (prevNpx != 0u && prevOut == 0u) { flush(prevFirst, prevNpx, prevSlot); prevNpx = 0u; }
         if (curNext >= curTotal && prevNpx == 0u) {
@@ -327,106 +454,46 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, RTD_
                 }
             }
         }
-        const unsigned long long idle = __builtin_amdgcn_ballot_w64(st == IDLE);
-        if (curNpx == 0u && prevNpx == 0u && exhausted && idle == ~0ull) break;
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(L.st == L_IDLE);
+        if (curNpx == 0u && prevNpx == 0u && exhausted && idle == ~0ull) break; // parked paths keep their range open, so none is left
 
-        // ---- refill from the current range ----
+        // ---- refill: parked paths, or items of the current range ----
         {
             const uint32_t nIdle = (uint32_t) __popcll(idle);
             const uint32_t avail = curTotal - curNext;
-            if (nIdle != 0u && avail != 0u && ((int) nIdle >= p.refill_lanes || nIdle == 64u)) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
+            if (nIdle != 0u && (avail != 0u || L.parked != 0u) && ((int) nIdle >= p.refill_lanes || nIdle == 64u)) {
+                const uint32_t rank = lane_rank(idle);
+                const uint32_t nUn = L.unpark_count(nIdle, avail != 0u);
                 if (COUNT) { ss.refill++; ss.refillLanes += nIdle; }
-                const uint32_t take = nIdle < avail ? nIdle : avail;
+                const uint32_t rest = nIdle - nUn;
+                const uint32_t take = rest < avail ? rest : avail;
                 bool started = false;
-                if (st == IDLE && rank < take) {
-                    const uint32_t item = curNext + rank;
-                    const uint32_t j = fastDiv ? div_uniform(item, n2, perRcp) : item / n2;
-                    const uint32_t smp = n1 + (item - j * n2);
-                    const RTD_AS3 uint32_t *pix = wv + curSlot * SW + 3u * P;
-                    const int row = (int) pix[j * 4 + 0], col = (int) pix[j * 4 + 1];
-                    const uint64_t pkey = (uint64_t) pix[j * 4 + 2] | ((uint64_t) pix[j * 4 + 3] << 32);
-                    rng = stream_for(pkey, smp);
-                    slotOff = curSlot * SW + j * 3u;
-                    colour = RTD_WHITE;
-                    bounces = 0;
-                    const CameraParams *cp = p.cam_ptr;
-                    asm volatile("" : "+s"(cp));
-                    if (camera_ray(*cp, row, col, rng, o, d)) {
-                        st = WALK;
-                        walk_begin(w, sc.first);
-                        started = true;
-                        if (COUNT) cnt.rays++;
+                if (L.st == L_IDLE) {
+                    if (rank < nUn) L.park_load(L.parked - 1u - rank);
+                    else if (rank - nUn < take) {
+                        const uint32_t item = curNext + (rank - nUn);
+                        const uint32_t j = fastDiv ? div_uniform(item, n2, perRcp) : item / n2;
+                        const uint32_t smp = n1 + (item - j * n2);
+                        const RTD_AS3 uint32_t *pix = wv + curSlot * SW + 3u * P;
+                        const int row = (int) pix[j * 4 + 0], col = (int) pix[j * 4 + 1];
+                        const uint64_t pkey = (uint64_t) pix[j * 4 + 2] | ((uint64_t) pix[j * 4 + 3] << 32);
+                        started = L.start_item(pkey, smp, row, col, curSlot * SW + j * 3u);
                     }
                 }
+                L.parked -= nUn;
                 curNext += take;
                 curOut += (uint32_t) __popcll(__builtin_amdgcn_ballot_w64(started));
             }
         }
-        const int nBusy = __popcll(__builtin_amdgcn_ballot_w64(st != IDLE));
-        if (nBusy == 0) continue;
+        if (__builtin_amdgcn_ballot_w64(L.st != L_IDLE) == 0ull) continue;
 
-        // ---- walk (as in run_items) ----
-        if (__builtin_amdgcn_ballot_w64(st == WALK) != 0ull) {
-            WalkCtx c = walk_ctx(d, w);
-            const int stop = (nBusy - p.yield_lanes) > 0 ? (nBusy - p.yield_lanes) : 0;
-            for (;;) {
-                for (;;) {
-                    const bool act = w.off < end;
-                    const int nAct = __popcll(__builtin_amdgcn_ballot_w64(act));
-                    if (nAct <= stop) break;
-                    if (COUNT) ss.trips++;
-                    if (act) {
-                        if (COUNT) cnt.aabb++;
-                        node_step<LDS>(sc, o, c, w);
-                    }
-                }
-                if (COUNT && __builtin_amdgcn_ballot_w64((w.off & RTD_LEAF) != 0) != 0ull) ss.leaf++;
-                if (w.off & RTD_LEAF) {
-                    if (COUNT) cnt.prim++;
-                    leaf_test<LDS>(sc, o, d, c, w);
-                }
-                const bool fin = (st == WALK) && (w.off >= end);
-                if (fin) st = DONE;
-                const int nWalk = __popcll(__builtin_amdgcn_ballot_w64(st == WALK));
-                const int nDone = __popcll(__builtin_amdgcn_ballot_w64(st == DONE));
-                if (nWalk == 0 || nDone >= p.yield_lanes) break;
-            }
-        }
-
-        // ---- finish (as in run_items) ----
-        if (COUNT) { const unsigned long long dm = __builtin_amdgcn_ballot_w64(st == DONE); if (dm) { ss.shade++; ss.shadeLanes += (uint32_t) __popcll(dm); } }
-        bool ended = false;
-        if (st == DONE) {
-            unbounded_tests<LDS, COUNT>(sc, o, d, w, cnt);
-            uint32_t result = RTD_BLACK;
-            if (w.best < 0) ended = true;
-            else {
-                V3 strike = walk(o, d, w.bestLen);
-                if (COUNT) cnt.refl++;
-                if (reflection<LDS>(sc, w.best, strike, o, d, colour, rng)) { ended = true; result = colour; }
-                else {
-                    bounces = bounces + 1;
-                    if (bounces > p.depth) { ended = true; result = RTD_HOTPINK; }
-                }
-            }
-            if (ended) {
-                if (result != 0u) {
-                    lds_add(wv + slotOff + 0, result & 0xFFu);
-                    lds_add(wv + slotOff + 1, (result >> 8) & 0xFFu);
-                    lds_add(wv + slotOff + 2, (result >> 16) & 0xFFu);
-                }
-                st = IDLE;
-                w.off = end;
-            } else {
-                st = WALK;
-                walk_begin(w, sc.first);
-                if (COUNT) cnt.rays++;
-            }
-        }
-        const bool inCur = (curNpx != 0u) && ((slotOff >= SW) == (curSlot == 1u));
-        curOut -= (uint32_t) __popcll(__builtin_amdgcn_ballot_w64(ended && inCur));
-        prevOut -= (uint32_t) __popcll(__builtin_amdgcn_ballot_w64(ended && !inCur));
+        L.stage_slow();
+        L.stage_walk();
+        L.stage_shade();
+        if (L.ended) L.add_result(wv + L.slotOff);
+        const bool inCur = (curNpx != 0u) && ((L.slotOff >= SW) == (curSlot == 1u));
+        curOut -= (uint32_t) __popcll(__builtin_amdgcn_ballot_w64(L.ended && inCur));
+        prevOut -= (uint32_t) __popcll(__builtin_amdgcn_ballot_w64(L.ended && !inCur));
     }
 }
 
@@ -434,7 +501,7 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, RTD_
 // MODE 1: pass A -- phase 1 and the decision for every pixel; pixels that continue are appended to `pairs` with the number of
 //         rays their 2k+1 samples took (a cost estimate), the others are final.
 // MODE 2: pass B -- phase 2 for the pixels of `live_list`, which the host-side launch sequence has ordered by decreasing cost
-//         (longest job first); unit size shrinks with the remaining list, down to one pixel.
+//         (longest job first); run_stream.
 // Per-pixel cost is heavy-tailed (a pixel on a glass sphere: ~20 rays per sample, 4 ms of one wave), so when a shard has only a few
 // units per wave the fused kernel ends with most waves waiting for a few long units started late; A + sort + B removes that tail.
 // Every mode computes the same integers: which wave traces which sample when has no effect (streams are per item).
@@ -468,6 +535,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     RTD_AS3 uint32_t *acc = wv;
     RTD_AS3 uint32_t *pix = wv + 6u * P;
     RTD_AS3 uint32_t *live = pix + 4u * P;
+    unsigned char *pool = p.park_pool + ((size_t) blockIdx.x * (BLOCK / 64) + (size_t) wave) * (size_t) RTD_PARK_ENTRY_BYTES * (size_t) p.park;
 
     const uint64_t nLocal = (uint64_t) p.n_rows * (uint64_t) p.cols;
     const uint32_t k = (uint32_t) p.k;
@@ -477,43 +545,26 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
 
     const unsigned long long tStart = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
     Counters cnt; cnt.rays = cnt.aabb = cnt.prim = cnt.refl = 0;
-    StageStats ss; ss.refill = ss.trips = ss.leaf = ss.shade = ss.refillLanes = ss.shadeLanes = 0;
+    StageStats ss; ss.refill = ss.trips = ss.leaf = ss.shade = ss.refillLanes = ss.shadeLanes = ss.slow = ss.slowLanes = ss.parkedLanes = 0;
     uint32_t earlyCount = 0;
     uint64_t sampleCount = 0; // Scene.traceOnce calls = sum of PixelStats.Count
 
-    if (MODE == 2) run_stream<LDS, COUNT>(p, sc, wv, n1, n2, cnt, ss, sampleCount);
+    if (MODE == 2) run_stream<LDS, COUNT>(p, sc, pool, wv, n1, n2, cnt, ss, sampleCount);
     else
     for (;;) {
-        unsigned long long first = 0;
-        uint32_t npx = 0;
-        if (MODE == 2) {
-            const unsigned long long nList = 0ull; // (pass B runs run_stream; this branch is dead code kept for the template)
-            if (lane == 0) {
-                const unsigned long long seen = __hip_atomic_load(p.queue_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (seen < nList) {
-                    unsigned long long want = (nList - seen) / (2ull * p.total_waves);
-                    want = want < 1ull ? 1ull : (want > (unsigned long long) P ? (unsigned long long) P : want);
-                    first = atomicAdd(p.queue_b, want);
-                    if (first < nList) npx = (uint32_t) ((nList - first < want) ? (nList - first) : want);
-                }
-            }
-            npx = __builtin_amdgcn_readfirstlane(npx);
-            first = ((unsigned long long) __builtin_amdgcn_readfirstlane((uint32_t) (first >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t) first);
-        } else {
-            uint32_t unit = 0;
-            if (lane == 0) unit = atomicAdd(p.queue, 1u);
-            unit = __builtin_amdgcn_readfirstlane(unit);
-            first = (unsigned long long) unit * P;
-            if (first < nLocal) npx = (uint32_t) ((nLocal - first < (unsigned long long) P) ? (nLocal - first) : (unsigned long long) P);
-        }
-        if (npx == 0u) break;
+        uint32_t unit = 0;
+        if (lane == 0) unit = atomicAdd(p.queue, 1u);
+        unit = __builtin_amdgcn_readfirstlane(unit);
+        const unsigned long long first = (unsigned long long) unit * P;
+        if (first >= nLocal) break;
+        const uint32_t npx = (uint32_t) ((nLocal - first < (unsigned long long) P) ? (nLocal - first) : (unsigned long long) P);
 
         // per-pixel coordinates (Scene.fs:219,226) and stream key; clear the accumulators
         for (uint32_t i = (uint32_t) lane; i < 6u * P; i += 64u) acc[i] = 0u;
         if (MODE == 1 && (uint32_t) lane < P) acc[11u * P + lane] = 0u;
         unsigned long long lp = 0; // local pixel of lane j < npx
         if ((uint32_t) lane < npx) {
-            lp = (MODE == 2) ? (unsigned long long) p.live_list[first + (uint32_t) lane] : first + (uint32_t) lane;
+            lp = first + (uint32_t) lane;
             uint32_t lr = (uint32_t) (lp / (unsigned long long) p.cols);
             uint32_t c = (uint32_t) (lp - (unsigned long long) lr * (unsigned long long) p.cols);
             uint32_t r = (uint32_t) p.row_first + lr * (uint32_t) p.row_stride;
@@ -525,71 +576,55 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
         }
         __builtin_amdgcn_wave_barrier();
 
+        // ---- phase 1: 2k+1 samples per pixel, sums split after sample k (Scene.fs:172-182) ----
+        run_items<LDS, COUNT, MODE == 1>(p, sc, pool, acc, pix, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- decide (Scene.fs:177-188) and compact the pixels that continue ----
         int sumR = 0, sumG = 0, sumB = 0, count = 0;
         bool cont = false;
-        uint32_t nLive = 0;
-        if (MODE != 2) {
-            // ---- phase 1: 2k+1 samples per pixel, sums split after sample k (Scene.fs:172-182) ----
-            run_items<LDS, COUNT, MODE == 1>(p, sc, acc, pix, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
-            __builtin_amdgcn_wave_barrier();
-
-            // ---- decide (Scene.fs:177-188) and compact the pixels that continue ----
-            if ((uint32_t) lane < npx) {
-                int aR = (int) lds_take(acc + lane * 3 + 0), aG = (int) lds_take(acc + lane * 3 + 1), aB = (int) lds_take(acc + lane * 3 + 2);
-                int bR = (int) lds_take(acc + P * 3 + lane * 3 + 0), bG = (int) lds_take(acc + P * 3 + lane * 3 + 1),
-                    bB = (int) lds_take(acc + P * 3 + lane * 3 + 2);
-                int c1 = (int) k + 1;
-                count = (int) n1;
-                sumR = aR + bR; sumG = aG + bG; sumB = aB + bB;
-                // PixelStats.mean (Pixel.fs:103-108) is integer division; Pixel.difference (Pixel.fs:113-116) is L1
-                int oR = (aR / c1) & 0xFF, oG = (aG / c1) & 0xFF, oB = (aB / c1) & 0xFF;
-                int nR = (sumR / count) & 0xFF, nG = (sumG / count) & 0xFF, nB = (sumB / count) & 0xFF;
-                int diff = abs(nR - oR) + abs(nG - oG) + abs(nB - oB);
-                if (diff == 0) earlyCount++;
-                cont = (diff != 0) && (n2 > 0u);
-            }
-            const unsigned long long liveMask = __builtin_amdgcn_ballot_w64(cont);
-            nLive = (uint32_t) __popcll(liveMask);
-            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (liveMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) liveMask, 0u));
-            if (MODE == 0) {
-                if (cont) live[pos] = (uint32_t) lane;
-            } else if (nLive > 0u) { // pass A: hand the pixel over to pass B, with its cost estimate
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(p.live_count, nLive);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (cont) p.pairs[base + pos] = ((unsigned long long) acc[11u * P + lane] << 32) | (unsigned long long) (uint32_t) lp;
-            }
-            __builtin_amdgcn_wave_barrier();
+        if ((uint32_t) lane < npx) {
+            int aR = (int) lds_take(acc + lane * 3 + 0), aG = (int) lds_take(acc + lane * 3 + 1), aB = (int) lds_take(acc + lane * 3 + 2);
+            int bR = (int) lds_take(acc + P * 3 + lane * 3 + 0), bG = (int) lds_take(acc + P * 3 + lane * 3 + 1),
+                bB = (int) lds_take(acc + P * 3 + lane * 3 + 2);
+            int c1 = (int) k + 1;
+            count = (int) n1;
+            sumR = aR + bR; sumG = aG + bG; sumB = aB + bB;
+            // PixelStats.mean (Pixel.fs:103-108) is integer division; Pixel.difference (Pixel.fs:113-116) is L1
+            int oR = (aR / c1) & 0xFF, oG = (aG / c1) & 0xFF, oB = (aB / c1) & 0xFF;
+            int nR = (sumR / count) & 0xFF, nG = (sumG / count) & 0xFF, nB = (sumB / count) & 0xFF;
+            int diff = abs(nR - oR) + abs(nG - oG) + abs(nB - oB);
+            if (diff == 0) earlyCount++;
+            cont = (diff != 0) && (n2 > 0u);
         }
+        const unsigned long long liveMask = __builtin_amdgcn_ballot_w64(cont);
+        const uint32_t nLive = (uint32_t) __popcll(liveMask);
+        const uint32_t pos = lane_rank(liveMask);
+        if (MODE == 0) {
+            if (cont) live[pos] = (uint32_t) lane;
+        } else if (nLive > 0u) { // pass A: hand the pixel over to pass B, with its cost estimate
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(p.live_count, nLive);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (cont) p.pairs[base + pos] = ((unsigned long long) acc[11u * P + lane] << 32) | (unsigned long long) (uint32_t) lp;
+        }
+        __builtin_amdgcn_wave_barrier();
 
         // ---- phase 2: the remaining spp-2k-1 samples of the surviving pixels (Scene.fs:191-192) ----
         if (MODE == 0 && nLive > 0u) {
-            run_items<LDS, COUNT, false>(p, sc, acc, pix, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (MODE == 2) {
-            run_items<LDS, COUNT, false>(p, sc, acc, pix, live, false, npx * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
+            run_items<LDS, COUNT, false>(p, sc, pool, acc, pix, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
             __builtin_amdgcn_wave_barrier();
         }
 
         // ---- PixelStats and mean out: one 16-byte store per pixel ----
         if ((uint32_t) lane < npx) {
-            if (MODE == 2) { // add phase 2 to what pass A left (this wave is the only writer of the pixel)
-                const i4 prev = ((const i4 *) p.accum)[lp];
-                sumR = prev.y + (int) lds_take(acc + lane * 3 + 0);
-                sumG = prev.z + (int) lds_take(acc + lane * 3 + 1);
-                sumB = prev.w + (int) lds_take(acc + lane * 3 + 2);
-                count = prev.x + (int) n2;
-                sampleCount += (uint64_t) n2;
-            } else {
-                if (MODE == 0 && cont) {
-                    sumR += (int) lds_take(acc + lane * 3 + 0);
-                    sumG += (int) lds_take(acc + lane * 3 + 1);
-                    sumB += (int) lds_take(acc + lane * 3 + 2);
-                    count += (int) n2;
-                }
-                sampleCount += (uint64_t) count;
+            if (MODE == 0 && cont) {
+                sumR += (int) lds_take(acc + lane * 3 + 0);
+                sumG += (int) lds_take(acc + lane * 3 + 1);
+                sumB += (int) lds_take(acc + lane * 3 + 2);
+                count += (int) n2;
             }
+            sampleCount += (uint64_t) count;
             i4 out; out.x = count; out.y = sumR; out.z = sumG; out.w = sumB;
             ((i4 *) p.accum)[lp] = out;
             if (p.rgb) {
@@ -601,7 +636,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
         __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- counters: one wave reduction and <= 6 atomics per wave per launch ----
+    // ---- counters: one wave reduction and a few atomics per wave per launch ----
     uint64_t e = wave_sum_u64(earlyCount), s = wave_sum_u64(sampleCount);
     if (COUNT) {
         uint64_t a = wave_sum_u64(cnt.rays), b = wave_sum_u64(cnt.aabb), c = wave_sum_u64(cnt.prim), dd = wave_sum_u64(cnt.refl);
@@ -616,6 +651,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
             atomicAdd(&p.counters[11], (unsigned long long) ss.shade);
             atomicAdd(&p.counters[12], (unsigned long long) ss.refillLanes);
             atomicAdd(&p.counters[13], (unsigned long long) ss.shadeLanes);
+            atomicAdd(&p.counters[20], (unsigned long long) ss.slow);
+            atomicAdd(&p.counters[21], (unsigned long long) ss.slowLanes);
+            atomicAdd(&p.counters[22], (unsigned long long) ss.parkedLanes);
             const unsigned long long tEnd = __builtin_amdgcn_s_memrealtime();
             atomicAdd(&p.counters[14], tEnd - tStart);                         // sum of wave lifetimes
             atomicMax(&p.counters[15], tEnd);                                  // last wave to finish

@@ -8,7 +8,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
+#include <atomic>
 #include <chrono>
+#include <cstddef>
 #include <cstdio>
 #include <map>
 #include <memory>
@@ -34,14 +38,25 @@ static int visible_devices() {
     if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); return 0; }
     return n;
 }
-static int need_device(int device) {
-    const int n = visible_devices();
-    if (n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible: the render path has no CPU fallback");
-    if (device < 0 || device >= n) return fail(RT_ERR_INVALID_ARGUMENT, "device index out of range");
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
-    return RT_OK;
-}
+// Makes `device` current for the lifetime of the guard and puts the caller's device back afterwards (a torch caller that
+// renders on another device than its current one must not find its later work redirected).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    int enter(int device) {
+        const int n = visible_devices();
+        if (n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible: the render path has no CPU fallback");
+        if (device < 0 || device >= n) return fail(RT_ERR_INVALID_ARGUMENT, "device index out of range");
+        if (hipGetDevice(&prev) != hipSuccess) { (void) hipGetLastError(); prev = -1; }
+        if (prev != device) {
+            hipError_t e = hipSetDevice(device);
+            if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+            switched = true;
+        }
+        return RT_OK;
+    }
+    ~DeviceGuard() { if (switched && prev >= 0) (void) hipSetDevice(prev); }
+};
 
 // ------------------------------------------------------------------------------------------------------------
 // scene handle: host image + lazily created per-device copies
@@ -50,11 +65,10 @@ struct DeviceScene {
     unsigned char *image = nullptr;
     TexRec *tex = nullptr;
     uint8_t *texels = nullptr;
-    unsigned char *scratch = nullptr; // ring of 512-byte {counters[16], queues, camera} slots
-    unsigned next_slot = 0;
     int cu_count = 0;
 };
-#define RT_SCRATCH_SLOTS 64
+// Per-launch scratch, stream-ordered (hipMallocAsync on the launch stream): counters[16] | queues | camera.  Nothing is
+// shared between launches, so any number of them may be in flight on any streams.
 #define RT_SCRATCH_BYTES 512
 
 struct rt_scene {
@@ -63,10 +77,13 @@ struct rt_scene {
     std::mutex mu;
 };
 
-static unsigned long long g_last_stage_stats[9] = {0};
-static int g_block_threads = 0, g_chunk_pixels = 0, g_blocks_per_cu = 0, g_yield_lanes = 0, g_refill_lanes = 0;
-static int g_passes = 0; // 0 auto, 1 fused kernel, 2 two-pass (A, sort, B)
-static int g_walk_tree = RT_WALK_TREE_SAH;
+// Process-wide DEFAULTS of the launch settings (rt_set_*): read once per call, and only for the rt_render_options fields a
+// caller leaves at 0.
+static std::atomic<int> g_block_threads{0}, g_chunk_pixels{0}, g_blocks_per_cu{0}, g_yield_lanes{0}, g_refill_lanes{0};
+static std::atomic<int> g_passes{0}; // 0 auto, 1 fused kernel, 2 two-pass (A, sort, B)
+static std::atomic<int> g_park_lanes{0};
+static std::atomic<int> g_walk_tree{RT_WALK_TREE_SAH};
+static thread_local unsigned long long g_last_stage_stats[12] = {0};
 
 static int device_scene(rt_scene *s, int device, DeviceScene **out) {
     std::lock_guard<std::mutex> lock(s->mu);
@@ -84,7 +101,6 @@ static int device_scene(rt_scene *s, int device, DeviceScene **out) {
         HIP_TRY(hipMalloc((void **) &d.texels, h.texelBlob.size()));
         HIP_TRY(hipMemcpy(d.texels, h.texelBlob.data(), h.texelBlob.size(), hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMalloc((void **) &d.scratch, RT_SCRATCH_SLOTS * RT_SCRATCH_BYTES));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     d.cu_count = prop.multiProcessorCount;
@@ -93,11 +109,53 @@ static int device_scene(rt_scene *s, int device, DeviceScene **out) {
     return RT_OK;
 }
 
-// LDS budget: 160 KiB per CU (MI355X_MICROARCH.md); the scene image plus every wave's scratch must fit one workgroup.
+// ------------------------------------------------------------------------------------------------------------
+// launch plan: ONE place decides block size, unit sizes, LDS residency and the number of passes -- the launch uses it and
+// rt_scene_get_info reports from it, so the two cannot disagree
+// ------------------------------------------------------------------------------------------------------------
+// LDS budget: 160 KiB per CU (MI355X_MICROARCH.md); the LDS part of the scene image plus every wave's scratch must fit one workgroup.
 #define RT_LDS_BYTES 163840u
-static bool lds_fits(const rth::HostScene &h, int block_threads, int chunk) {
-    const uint32_t waves = (uint32_t) block_threads / 64u;
-    return (uint64_t) h.off.total + (uint64_t) waves * RTD_WAVE_WORDS(chunk) * 4u <= RT_LDS_BYTES;
+struct Settings { int block, chunk, blocks_per_cu, yield, refill, passes, park; };
+static Settings resolve_settings(const rt_render_options *o) {
+    rt_render_options v{};
+    if (o) memcpy(&v, o, o->struct_size < sizeof(v) ? o->struct_size : sizeof(v));
+    Settings s;
+    s.block = v.block_threads ? v.block_threads : g_block_threads.load();
+    s.chunk = v.chunk_pixels ? v.chunk_pixels : g_chunk_pixels.load();
+    s.blocks_per_cu = v.blocks_per_cu ? v.blocks_per_cu : g_blocks_per_cu.load();
+    s.yield = v.yield_lanes ? v.yield_lanes : g_yield_lanes.load();
+    s.refill = v.refill_lanes ? v.refill_lanes : g_refill_lanes.load();
+    s.passes = v.passes ? v.passes : g_passes.load();
+    s.park = v.park_lanes ? v.park_lanes : g_park_lanes.load();
+    return s;
+}
+static const char *check_settings(const Settings &s) {
+    if (s.block != 0 && s.block != 256 && s.block != 512 && s.block != 768 && s.block != 1024) return "block_threads must be 0, 256, 512, 768 or 1024";
+    if (s.chunk < 0 || s.chunk > RTD_MAX_CHUNK) return "chunk_pixels must be in [0, 64]";
+    if (s.blocks_per_cu < 0 || s.blocks_per_cu > 8) return "blocks_per_cu must be in [0, 8]";
+    if (s.yield < 0 || s.yield > 64 || s.refill < 0 || s.refill > 64) return "thresholds must be in [0, 64]";
+    if (s.passes < 0 || s.passes > 2) return "passes must be 0 (auto), 1 (fused) or 2 (two-pass)";
+    if (s.park < -1 || s.park > RTD_MAX_PARK) return "park_lanes must be in [-1, 256]";
+    return nullptr;
+}
+static size_t lds_need(const rth::HostScene &h, bool lds, int block, int chunk) {
+    return (lds ? (size_t) h.off.total : 0u) + (size_t) (block / 64) * RTD_WAVE_WORDS(chunk) * 4u;
+}
+struct LaunchPlan {
+    int block = 1024, chunk = 16, park = 0;
+    bool lds = false;
+};
+// Block size and residency for a scene: the preferred block if the LDS image fits beside the waves' scratch, else 256
+// threads if that fits, else the global-memory variant of the kernel at the preferred block.
+static LaunchPlan plan_launch(const rth::HostScene &h, const Settings &s) {
+    LaunchPlan p;
+    p.block = s.block ? s.block : 1024;
+    p.chunk = s.chunk ? s.chunk : 16;
+    p.park = s.park < 0 ? 0 : (s.park ? s.park : RTD_PARK_DEFAULT);
+    auto fits = [&](int block, int chunk) { return lds_need(h, true, block, chunk) <= RT_LDS_BYTES; };
+    if (fits(p.block, p.chunk)) { p.lds = true; return p; }
+    if (p.block > 256 && fits(256, p.chunk)) { p.block = 256; p.lds = true; return p; }
+    return p; // global-memory variant: LDS holds only the waves' scratch, which always fits
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -124,6 +182,14 @@ static render_fn pick_kernel(bool lds, bool count, int block, int mode) {
     return mode == 0 ? pick_mode<0>(lds, count, block) : (mode == 1 ? pick_mode<1>(lds, count, block) : pick_mode<2>(lds, count, block));
 }
 
+// Zeroes a launch's counters and queues and writes its camera: one tiny launch instead of a memset plus a copy from
+// pageable host memory (which may block the host until earlier work on the stream has finished).
+__global__ void launch_init_kernel(unsigned char *scratch, const CameraParams cam) {
+    if (threadIdx.x < 64) ((unsigned int *) scratch)[threadIdx.x] = 0u; // 256 B: counters[16], queue, queue_b, live_count
+    if (threadIdx.x == 0) *(CameraParams *) (scratch + 256) = cam;
+}
+static_assert(sizeof(CameraParams) <= RT_SCRATCH_BYTES - 256, "camera must fit the scratch slot");
+
 extern "C" {
 
 int rt_abi_version(void) { return RT_ABI_VERSION; }
@@ -137,26 +203,52 @@ size_t rt_abi_sizeof(int which) {
     case 2: return sizeof(rt_camera);
     case 3: return sizeof(rt_scene_info);
     case 4: return sizeof(rt_stats);
+    case 5: return sizeof(rt_render_options);
+    case 6: return sizeof(rt_scene_options);
     default: return 0;
     }
 }
 
+size_t rt_abi_offsetof(int which, int field) {
+#define RT_OFFS(T, ...) { static const size_t o[] = {__VA_ARGS__}; return (field >= 0 && (size_t) field < sizeof(o) / sizeof(o[0])) ? o[field] : (size_t) -1; }
+#define F(T, m) offsetof(T, m)
+    switch (which) {
+    case 0: RT_OFFS(rt_hittable, F(rt_hittable, kind), F(rt_hittable, style), F(rt_hittable, point), F(rt_hittable, normal), F(rt_hittable, radius),
+                    F(rt_hittable, albedo), F(rt_hittable, fuzz), F(rt_hittable, ior), F(rt_hittable, prob), F(rt_hittable, rgb), F(rt_hittable, reserved),
+                    F(rt_hittable, texture))
+    case 1: RT_OFFS(rt_texture, F(rt_texture, kind), F(rt_texture, rgb), F(rt_texture, ramp_src), F(rt_texture, reserved), F(rt_texture, even),
+                    F(rt_texture, odd), F(rt_texture, grid_size), F(rt_texture, width), F(rt_texture, height), F(rt_texture, texels),
+                    F(rt_texture, map_centre), F(rt_texture, map_radius))
+    case 2: RT_OFFS(rt_camera, F(rt_camera, view_origin), F(rt_camera, view_dir), F(rt_camera, xaxis_origin), F(rt_camera, xaxis_dir),
+                    F(rt_camera, yaxis_origin), F(rt_camera, yaxis_dir), F(rt_camera, viewport_width), F(rt_camera, viewport_height),
+                    F(rt_camera, focal_length), F(rt_camera, samples_per_pixel), F(rt_camera, bounce_depth))
+    case 3: RT_OFFS(rt_scene_info, F(rt_scene_info, n_bounded), F(rt_scene_info, n_unbounded), F(rt_scene_info, n_nodes), F(rt_scene_info, tree_depth),
+                    F(rt_scene_info, n_textures), F(rt_scene_info, lds_resident), F(rt_scene_info, walk_tree), F(rt_scene_info, walk_tree_depth),
+                    F(rt_scene_info, scene_bytes), F(rt_scene_info, texel_bytes))
+    case 4: RT_OFFS(rt_stats, F(rt_stats, rays), F(rt_stats, aabb_tests), F(rt_stats, prim_tests), F(rt_stats, reflections), F(rt_stats, samples),
+                    F(rt_stats, pixels), F(rt_stats, pixels_early), F(rt_stats, kernel_ms), F(rt_stats, total_ms))
+    case 5: RT_OFFS(rt_render_options, F(rt_render_options, struct_size), F(rt_render_options, block_threads), F(rt_render_options, chunk_pixels),
+                    F(rt_render_options, blocks_per_cu), F(rt_render_options, yield_lanes), F(rt_render_options, refill_lanes),
+                    F(rt_render_options, passes), F(rt_render_options, park_lanes))
+    case 6: RT_OFFS(rt_scene_options, F(rt_scene_options, struct_size), F(rt_scene_options, walk_tree))
+    default: return (size_t) -1;
+    }
+#undef F
+#undef RT_OFFS
+}
+
 int rt_set_launch_config(int32_t block_threads, int32_t chunk_pixels, int32_t blocks_per_cu) {
-    if (block_threads != 0 && block_threads != 256 && block_threads != 512 && block_threads != 768 && block_threads != 1024)
-        return fail(RT_ERR_INVALID_ARGUMENT, "block_threads must be 0, 256, 512, 768 or 1024");
-    if (chunk_pixels < 0 || chunk_pixels > RTD_MAX_CHUNK) return fail(RT_ERR_INVALID_ARGUMENT, "chunk_pixels must be in [0, 64]");
-    if (blocks_per_cu < 0 || blocks_per_cu > 8) return fail(RT_ERR_INVALID_ARGUMENT, "blocks_per_cu must be in [0, 8]");
+    Settings s{block_threads, chunk_pixels, blocks_per_cu, 0, 0, 0, 0};
+    if (const char *m = check_settings(s)) return fail(RT_ERR_INVALID_ARGUMENT, m);
     g_block_threads = block_threads;
     g_chunk_pixels = chunk_pixels;
     g_blocks_per_cu = blocks_per_cu;
     return RT_OK;
 }
 
-/* Diagnostic: wave-level stage executions of the last render with RT_RENDER_COUNTERS on this process:
- * refill stages, node trips, leaf stages, shade stages, lanes refilled, lanes shaded. */
-int rt_last_stage_stats(uint64_t out[9]) {
+int rt_last_stage_stats(uint64_t out[12]) {
     if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
-    for (int i = 0; i < 9; ++i) out[i] = g_last_stage_stats[i];
+    for (int i = 0; i < 12; ++i) out[i] = g_last_stage_stats[i];
     return RT_OK;
 }
 
@@ -168,6 +260,11 @@ int rt_set_walk_tree(int32_t kind) {
 int rt_set_passes(int32_t passes) {
     if (passes < 0 || passes > 2) return fail(RT_ERR_INVALID_ARGUMENT, "passes must be 0 (auto), 1 (fused) or 2 (two-pass)");
     g_passes = passes;
+    return RT_OK;
+}
+int rt_set_park(int32_t park_lanes) {
+    if (park_lanes < -1 || park_lanes > RTD_MAX_PARK) return fail(RT_ERR_INVALID_ARGUMENT, "park_lanes must be in [-1, 256]");
+    g_park_lanes = park_lanes;
     return RT_OK;
 }
 
@@ -186,25 +283,35 @@ int rt_camera_make_basic(int32_t spp, double focal, double aspect, const double 
     return RT_OK;
 }
 
-int rt_scene_create(const rt_hittable *hittables, size_t n_hittables, const rt_texture *textures, size_t n_textures, rt_scene **out) {
+int rt_scene_create_ex(const rt_hittable *hittables, size_t n_hittables, const rt_texture *textures, size_t n_textures,
+                       const rt_scene_options *options, rt_scene **out) {
     if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
+    int walk = -1;
+    if (options && options->struct_size >= offsetof(rt_scene_options, walk_tree) + sizeof(int32_t)) walk = options->walk_tree;
+    if (walk == -1) walk = g_walk_tree.load();
+    if (walk != RT_WALK_TREE_SAH && walk != RT_WALK_TREE_REFERENCE) return fail(RT_ERR_INVALID_ARGUMENT, "walk_tree must be RT_WALK_TREE_SAH, RT_WALK_TREE_REFERENCE or -1");
     std::unique_ptr<rt_scene> s(new rt_scene());
     int status = RT_OK;
-    std::string msg = rth::build_scene(hittables, n_hittables, textures, n_textures, g_walk_tree, s->host, status);
+    std::string msg = rth::build_scene(hittables, n_hittables, textures, n_textures, walk, s->host, status);
     if (status != RT_OK) return fail(status, msg);
     *out = s.release();
     return RT_OK;
 }
+int rt_scene_create(const rt_hittable *hittables, size_t n_hittables, const rt_texture *textures, size_t n_textures, rt_scene **out) {
+    return rt_scene_create_ex(hittables, n_hittables, textures, n_textures, nullptr, out);
+}
 
 void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) { (void) hipGetLastError(); prev = -1; }
     for (auto &kv : s->dev) {
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         (void) hipFree(kv.second.image);
         (void) hipFree(kv.second.tex);
         (void) hipFree(kv.second.texels);
-        (void) hipFree(kv.second.scratch);
     }
+    if (prev >= 0 && !s->dev.empty()) (void) hipSetDevice(prev);
     delete s;
 }
 
@@ -218,7 +325,7 @@ int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
     out->walk_tree = h.walkKind;
     out->walk_tree_depth = h.walkTree.depth;
     out->n_textures = (int32_t) h.texRecs.size();
-    out->lds_resident = lds_fits(h, g_block_threads ? g_block_threads : 1024, g_chunk_pixels ? g_chunk_pixels : 16) ? 1 : 0;
+    out->lds_resident = plan_launch(h, resolve_settings(nullptr)).lds ? 1 : 0; // the decision a render with default options takes
     out->scene_bytes = (int64_t) h.off.total;
     out->texel_bytes = (int64_t) h.texelBlob.size();
     return RT_OK;
@@ -249,20 +356,49 @@ static int check_geometry(const rt_camera *camera, int32_t max_w, int32_t max_h,
     if (camera->samples_per_pixel < 1) return fail(RT_ERR_INVALID_ARGUMENT, "samples_per_pixel must be >= 1");
     if (camera->samples_per_pixel > 8000000) return fail(RT_ERR_INVALID_ARGUMENT, "samples_per_pixel too large for int32 sums (255*spp)");
     if (camera->bounce_depth < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bounce_depth must be >= 0");
+    if (camera->bounce_depth > 0xFFFFFF) return fail(RT_ERR_INVALID_ARGUMENT, "bounce_depth too large");
     const int rows = 2 * max_h + 1;
     if (row_stride <= 0 || row_first < 0 || n_rows < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad row shard");
     if (n_rows > 0 && (int64_t) row_first + (int64_t) (n_rows - 1) * row_stride >= rows) return fail(RT_ERR_INVALID_ARGUMENT, "row shard exceeds the image");
     return RT_OK;
 }
 
-int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max_w, int32_t max_h, uint64_t seed, int32_t device,
-                     int32_t row_first, int32_t row_stride, int32_t n_rows, uint32_t flags, void *d_accum, void *d_rgb, void *stream,
-                     rt_stats *stats) {
+} // extern "C"
+
+// What a launch leaves behind when its statistics are wanted: events around the kernels and the launch's scratch, which
+// then stays allocated until the counters have been read.
+struct Pending {
+    hipEvent_t a = nullptr, b = nullptr;
+    unsigned char *scr = nullptr;
+    hipStream_t st = nullptr;
+    int device = -1;
+    uint64_t pixels = 0, waves = 0;
+    bool launched = false, keep = false;
+    std::chrono::steady_clock::time_point t0;
+    void release() { // events destroyed, scratch handed back to the stream's pool in stream order
+        if (a) (void) hipEventDestroy(a);
+        if (b) (void) hipEventDestroy(b);
+        if (scr) (void) hipFreeAsync(scr, st);
+        a = b = nullptr; scr = nullptr;
+    }
+    ~Pending() { release(); }
+};
+
+// Enqueues one shard's render on `stream`; never waits for the device.  With want_stats the launch is bracketed by events
+// and its scratch is kept in `pd` for collect_stats.
+static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t max_w, int32_t max_h, uint64_t seed, int32_t device,
+                         int32_t row_first, int32_t row_stride, int32_t n_rows, uint32_t flags, void *d_accum, void *d_rgb, void *stream,
+                         const rt_render_options *options, bool want_stats, Pending &pd) {
+    rt_stats *stats = want_stats ? (rt_stats *) 1 : nullptr; // only tested for NULL below
     if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
     int rc = check_geometry(camera, max_w, max_h, row_first, row_stride, n_rows);
     if (rc != RT_OK) return rc;
     if (n_rows > 0 && !d_accum) return fail(RT_ERR_INVALID_ARGUMENT, "d_accum is NULL");
-    rc = need_device(device);
+    if (options && options->struct_size < sizeof(uint32_t)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_options.struct_size is not set");
+    const Settings set = resolve_settings(options);
+    if (const char *m = check_settings(set)) return fail(RT_ERR_INVALID_ARGUMENT, m);
+    DeviceGuard guard;
+    rc = guard.enter(device);
     if (rc != RT_OK) return rc;
     const auto t0 = std::chrono::steady_clock::now();
     DeviceScene *ds = nullptr;
@@ -271,11 +407,10 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     const rth::HostScene &h = scene->host;
     hipStream_t st = (hipStream_t) stream;
 
-    int block = g_block_threads ? g_block_threads : 1024;
-    int chunk = g_chunk_pixels ? g_chunk_pixels : 16;
+    const LaunchPlan plan = plan_launch(h, set);
+    const int block = plan.block, chunk = plan.chunk;
+    const bool lds = plan.lds;
     const bool count = (flags & RT_RENDER_COUNTERS) != 0;
-    bool lds = lds_fits(h, block, chunk);
-    if (!lds && block > 256 && lds_fits(h, 256, chunk)) { block = 256; lds = true; }
 
     RenderParams p{};
     CameraParams hostCam{};
@@ -303,27 +438,19 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     const int half = camera->samples_per_pixel / 2;
     p.k = half < 5 ? half : 5; // min 5 (spp / 2), Scene.fs:172
     p.chunk = chunk;
-    p.yield_lanes = g_yield_lanes ? g_yield_lanes : RTD_YIELD_DEFAULT;
-    p.refill_lanes = g_refill_lanes ? g_refill_lanes : RTD_REFILL_DEFAULT;
+    p.park = plan.park;
+    p.yield_lanes = set.yield ? set.yield : RTD_YIELD_DEFAULT;
+    p.refill_lanes = set.refill ? set.refill : RTD_REFILL_DEFAULT;
     p.accum = (int32_t *) d_accum;
     p.rgb = (uint8_t *) d_rgb;
-    unsigned slot;
-    {
-        std::lock_guard<std::mutex> lock(const_cast<rt_scene *>(scene)->mu);
-        slot = ds->next_slot++ % RT_SCRATCH_SLOTS;
-    }
-    unsigned char *scr = ds->scratch + (size_t) slot * RT_SCRATCH_BYTES;
-    p.counters = (unsigned long long *) scr;
-    p.queue = (unsigned int *) (scr + 128);
-    p.cam_ptr = (const CameraParams *) (scr + 256);
 
-    const size_t ldsBytes = (lds ? (size_t) h.off.total : 0u) + (size_t) (block / 64) * RTD_WAVE_WORDS(chunk) * 4u;
     render_fn fn = pick_kernel(lds, count, block, 0);
+    const size_t ldsBytes = lds_need(h, lds, block, chunk);
     HIP_TRY(hipFuncSetAttribute((const void *) fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes));
     int perCu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, (const void *) fn, block, ldsBytes));
     if (perCu < 1) return fail(RT_ERR_HIP, "render kernel does not fit on a CU (occupancy 0)");
-    if (g_blocks_per_cu > 0 && g_blocks_per_cu < perCu) perCu = g_blocks_per_cu;
+    if (set.blocks_per_cu > 0 && set.blocks_per_cu < perCu) perCu = set.blocks_per_cu;
     const uint64_t nLocal = (uint64_t) n_rows * (uint64_t) p.cols;
     const uint64_t units = (nLocal + (uint64_t) chunk - 1) / (uint64_t) chunk;
     const uint64_t fullGrid = (uint64_t) ds->cu_count * (uint64_t) perCu;
@@ -339,31 +466,41 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     // two passes 3.5 ms; config 3's 1/8 shard, 500 spp: 51 ms against 30 ms).
     const int n2 = camera->samples_per_pixel - 2 * p.k - 1;
     const bool twoPass = n2 > 0 && nLocal > 0 && nLocal < (1ull << 32) &&
-                         (g_passes == 2 || (g_passes == 0 && n2 >= 128 && units < 64ull * fullGrid * wavesPerBlock));
+                         (set.passes == 2 || (set.passes == 0 && n2 >= 128 && units < 64ull * fullGrid * wavesPerBlock));
 
-    struct Events { // destroyed on every exit path
-        hipEvent_t a = nullptr, b = nullptr;
-        ~Events() { if (a) (void) hipEventDestroy(a); if (b) (void) hipEventDestroy(b); }
-    } ev;
+    // Everything below is stream-ordered: scratch and workspace come from the stream's pool and go back to it after the last
+    // launch that uses them, so no launch shares state with another and the call returns without waiting for the device.
+    const size_t pairsBytes = twoPass ? (((size_t) nLocal * 8u + 15u) & ~(size_t) 15u) : 0u, listBytes = twoPass ? (((size_t) nLocal * 4u + 15u) & ~(size_t) 15u) : 0u;
+    const size_t sortBytes = twoPass ? (3u * RTD_COST_BUCKETS * 4u + 15u) & ~(size_t) 15u : 0u;
+    const size_t poolBytes = (size_t) (twoPass ? fullGrid : grid) * (size_t) wavesPerBlock * (size_t) RTD_PARK_ENTRY_BYTES * (size_t) plan.park;
+    unsigned char *scr = nullptr;
+    if (grid > 0 || stats) HIP_TRY(hipMallocAsync((void **) &scr, RT_SCRATCH_BYTES + pairsBytes + listBytes + sortBytes + poolBytes, st));
+    Pending &cl = pd; // on every exit path its destructor (or collect_stats) gives the scratch back
+    cl.scr = scr; cl.st = st; cl.device = device; cl.t0 = t0;
+    cl.pixels = nLocal;
+    cl.waves = (twoPass ? fullGrid : grid) * wavesPerBlock;
     if (stats) {
-        HIP_TRY(hipEventCreate(&ev.a));
-        HIP_TRY(hipEventCreate(&ev.b));
+        HIP_TRY(hipEventCreate(&cl.a));
+        HIP_TRY(hipEventCreate(&cl.b));
     }
-    hipEvent_t &ev0 = ev.a, &ev1 = ev.b;
-    HIP_TRY(hipMemsetAsync(scr, 0, 256, st));
-    HIP_TRY(hipMemcpyAsync(scr + 256, &hostCam, sizeof(hostCam), hipMemcpyHostToDevice, st)); // pageable source: copied before return
+    unsigned char *ws = scr ? scr + RT_SCRATCH_BYTES : nullptr;
+    p.counters = (unsigned long long *) scr;
+    p.queue = (unsigned int *) (scr + 128);
+    p.cam_ptr = (const CameraParams *) (scr + 256);
+    p.park_pool = ws ? ws + pairsBytes + listBytes + sortBytes : nullptr;
+    if (scr) {
+        hipLaunchKernelGGL(launch_init_kernel, dim3(1), dim3(64), 0, st, scr, hostCam);
+        HIP_TRY(hipGetLastError());
+    }
     if (grid > 0) {
-        if (stats) HIP_TRY(hipEventRecord(ev0, st));
+        if (stats) HIP_TRY(hipEventRecord(cl.a, st));
         if (!twoPass) {
             hipLaunchKernelGGL(fn, dim3((unsigned) grid), dim3((unsigned) block), ldsBytes, st, p);
             HIP_TRY(hipGetLastError());
         } else {
-            // stream-ordered workspace: pairs[nLocal] u64, list[nLocal] u32, hist/offsets/cursor[64] u32
-            unsigned char *ws = nullptr;
-            const size_t pairsBytes = (size_t) nLocal * 8u, listBytes = ((size_t) nLocal * 4u + 15u) & ~(size_t) 15u, sortBytes = 3u * RTD_COST_BUCKETS * 4u;
-            HIP_TRY(hipMallocAsync((void **) &ws, pairsBytes + listBytes + sortBytes, st));
+            // workspace: pairs[nLocal] u64, list[nLocal] u32, hist/offsets/cursor[64] u32
             unsigned int *sortBuf = (unsigned int *) (ws + pairsBytes + listBytes);
-            hipError_t e = hipMemsetAsync(sortBuf, 0, sortBytes, st);
+            HIP_TRY(hipMemsetAsync(sortBuf, 0, sortBytes, st));
             p.pairs = (unsigned long long *) ws;
             p.live_list = (const unsigned int *) (ws + pairsBytes);
             p.queue_b = (unsigned long long *) (scr + 136);
@@ -373,57 +510,86 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
             // Unit sizes: pass A traces only 2k+1 samples per pixel, so its units are wide; pass B's largest unit is about a
             // sixteenth of a wave's share of the shard (measured best: 32 px at 1/2 frame, 16 at 1/4, 8 at 1/8 of config 3),
             // and shrinks towards the end of the cost-ordered list.
-            int chunkA = g_chunk_pixels ? g_chunk_pixels : 32, chunkB = g_chunk_pixels ? g_chunk_pixels : 4;
-            if (!g_chunk_pixels) {
+            int chunkA = set.chunk ? set.chunk : 32, chunkB = set.chunk ? set.chunk : 4;
+            if (!set.chunk) {
                 const uint64_t share = nLocal / (fullGrid * wavesPerBlock * 16u);
                 while (chunkB < 32 && (uint64_t) chunkB * 3u / 2u <= share) chunkB *= 2; // nearest power of two
             }
-            while (chunkA > 1 && !lds_fits(h, block, chunkA) && lds) chunkA /= 2;
-            const size_t ldsA = (lds ? (size_t) h.off.total : 0u) + (size_t) (block / 64) * RTD_WAVE_WORDS(chunkA) * 4u;
-            const size_t ldsB = (lds ? (size_t) h.off.total : 0u) + (size_t) (block / 64) * RTD_WAVE_WORDS(chunkB) * 4u;
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void *) fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsA);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void *) fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsB);
-            if (e == hipSuccess) {
-                RenderParams pa = p;
-                pa.chunk = chunkA;
-                const uint64_t unitsA = (nLocal + (uint64_t) chunkA - 1) / (uint64_t) chunkA;
-                uint64_t gridA = (unitsA + wavesPerBlock - 1) / wavesPerBlock;
-                if (gridA > fullGrid) gridA = fullGrid;
-                hipLaunchKernelGGL(fa, dim3((unsigned) gridA), dim3((unsigned) block), ldsA, st, pa);
-                p.chunk = chunkB;
-                hipLaunchKernelGGL(sort_hist_kernel, dim3(256), dim3(256), 0, st, (const unsigned long long *) p.pairs, (const unsigned int *) p.live_count,
-                                   (uint32_t) (2 * p.k + 1), sortBuf);
-                hipLaunchKernelGGL(sort_offsets_kernel, dim3(1), dim3(64), 0, st, (const unsigned int *) sortBuf, sortBuf + RTD_COST_BUCKETS);
-                hipLaunchKernelGGL(sort_scatter_kernel, dim3(256), dim3(256), 0, st, (const unsigned long long *) p.pairs, (const unsigned int *) p.live_count,
-                                   (uint32_t) (2 * p.k + 1), (const unsigned int *) (sortBuf + RTD_COST_BUCKETS), sortBuf + 2 * RTD_COST_BUCKETS,
-                                   (unsigned int *) (ws + pairsBytes));
-                hipLaunchKernelGGL(fb, dim3((unsigned) fullGrid), dim3((unsigned) block), ldsB, st, p);
-                e = hipGetLastError();
-            }
-            const hipError_t ef = hipFreeAsync(ws, st);
+            // both passes must fit the LDS beside the scene image, decided BEFORE anything is launched (a misfit found after
+            // pass A would leave a half-rendered buffer); 
+            while (lds && chunkA > 1 && lds_need(h, true, block, chunkA) > RT_LDS_BYTES) chunkA /= 2;
+            while (lds && chunkB > 1 && lds_need(h, true, block, chunkB) > RT_LDS_BYTES) chunkB /= 2;
+            const size_t ldsA = lds_need(h, lds, block, chunkA), ldsB = lds_need(h, lds, block, chunkB);
+            if (lds && (ldsA > RT_LDS_BYTES || ldsB > RT_LDS_BYTES)) return fail(RT_ERR_HIP, "two-pass launch does not fit the LDS");
+            HIP_TRY(hipFuncSetAttribute((const void *) fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsA));
+            HIP_TRY(hipFuncSetAttribute((const void *) fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsB));
+            RenderParams pa = p;
+            pa.chunk = chunkA;
+            const uint64_t unitsA = (nLocal + (uint64_t) chunkA - 1) / (uint64_t) chunkA;
+            uint64_t gridA = (unitsA + wavesPerBlock - 1) / wavesPerBlock;
+            if (gridA > fullGrid) gridA = fullGrid;
+            hipLaunchKernelGGL(fa, dim3((unsigned) gridA), dim3((unsigned) block), ldsA, st, pa);
+            p.chunk = chunkB;
+            hipLaunchKernelGGL(sort_hist_kernel, dim3(256), dim3(256), 0, st, (const unsigned long long *) p.pairs, (const unsigned int *) p.live_count,
+                               (uint32_t) (2 * p.k + 1), sortBuf);
+            hipLaunchKernelGGL(sort_offsets_kernel, dim3(1), dim3(64), 0, st, (const unsigned int *) sortBuf, sortBuf + RTD_COST_BUCKETS);
+            hipLaunchKernelGGL(sort_scatter_kernel, dim3(256), dim3(256), 0, st, (const unsigned long long *) p.pairs, (const unsigned int *) p.live_count,
+                               (uint32_t) (2 * p.k + 1), (const unsigned int *) (sortBuf + RTD_COST_BUCKETS), sortBuf + 2 * RTD_COST_BUCKETS,
+                               (unsigned int *) (ws + pairsBytes));
+            hipLaunchKernelGGL(fb, dim3((unsigned) fullGrid), dim3((unsigned) block), ldsB, st, p);
+            const hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("two-pass launch: ") + hipGetErrorString(e));
-            if (ef != hipSuccess) return fail(RT_ERR_HIP, std::string("hipFreeAsync: ") + hipGetErrorString(ef));
         }
-        if (stats) HIP_TRY(hipEventRecord(ev1, st));
+        if (stats) HIP_TRY(hipEventRecord(cl.b, st));
     }
-    if (stats) {
-        HIP_TRY(hipStreamSynchronize(st));
-        unsigned long long c[16] = {0};
-        HIP_TRY(hipMemcpy(c, scr, sizeof(c), hipMemcpyDeviceToHost));
-        for (int i = 0; i < 6; ++i) g_last_stage_stats[i] = c[8 + i];
-        g_last_stage_stats[6] = c[14];                                  // sum of wave lifetimes, 100 MHz ticks
-        g_last_stage_stats[7] = c[15] - (0x4000000000000000ull - c[7]); // first wave start -> last wave end, ticks
-        g_last_stage_stats[8] = (unsigned long long) (twoPass ? fullGrid : grid) * (unsigned long long) wavesPerBlock;
-        float ms = 0.f;
-        if (grid > 0) HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-        memset(stats, 0, sizeof(*stats));
-        stats->rays = c[0]; stats->aabb_tests = c[1]; stats->prim_tests = c[2]; stats->reflections = c[3];
-        stats->samples = c[4]; stats->pixels_early = c[5];
-        stats->pixels = nLocal;
-        stats->kernel_ms = ms;
-        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    }
+    cl.launched = grid > 0;
+    if (!stats) cl.release();
     return RT_OK;
+}
+
+// Waits for the launch's stream and reads its counters (the device of the launch must be current).
+static int collect_stats(Pending &pd, rt_stats *stats) {
+    HIP_TRY(hipStreamSynchronize(pd.st));
+    unsigned long long c[32] = {0};
+    if (pd.scr) {
+        HIP_TRY(hipMemcpy(c, pd.scr, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(c + 16, pd.scr + 160, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < 6; ++i) g_last_stage_stats[i] = c[8 + i];
+    g_last_stage_stats[6] = c[14];                                  // sum of wave lifetimes, 100 MHz ticks
+    g_last_stage_stats[7] = c[15] - (0x4000000000000000ull - c[7]); // first wave start -> last wave end, ticks
+    g_last_stage_stats[8] = pd.waves;
+    g_last_stage_stats[9] = c[16]; g_last_stage_stats[10] = c[17]; g_last_stage_stats[11] = c[18];
+    float ms = 0.f;
+    if (pd.launched) HIP_TRY(hipEventElapsedTime(&ms, pd.a, pd.b));
+    memset(stats, 0, sizeof(*stats));
+    stats->rays = c[0]; stats->aabb_tests = c[1]; stats->prim_tests = c[2]; stats->reflections = c[3];
+    stats->samples = c[4]; stats->pixels_early = c[5];
+    stats->pixels = pd.pixels;
+    stats->kernel_ms = ms;
+    stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pd.t0).count();
+    pd.release();
+    return RT_OK;
+}
+
+extern "C" {
+
+int rt_render_device_ex(const rt_scene *scene, const rt_camera *camera, int32_t max_w, int32_t max_h, uint64_t seed, int32_t device,
+                        int32_t row_first, int32_t row_stride, int32_t n_rows, uint32_t flags, void *d_accum, void *d_rgb, void *stream,
+                        const rt_render_options *options, rt_stats *stats) {
+    DeviceGuard guard; // entered again inside launch_render (a no-op then); kept here so that collect_stats runs on the device too
+    int rc = guard.enter(device);
+    if (rc != RT_OK) return rc;
+    Pending pd;
+    rc = launch_render(scene, camera, max_w, max_h, seed, device, row_first, row_stride, n_rows, flags, d_accum, d_rgb, stream, options, stats != nullptr, pd);
+    if (rc != RT_OK || !stats) return rc;
+    return collect_stats(pd, stats);
+}
+
+int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max_w, int32_t max_h, uint64_t seed, int32_t device,
+                     int32_t row_first, int32_t row_stride, int32_t n_rows, uint32_t flags, void *d_accum, void *d_rgb, void *stream,
+                     rt_stats *stats) {
+    return rt_render_device_ex(scene, camera, max_w, max_h, seed, device, row_first, row_stride, n_rows, flags, d_accum, d_rgb, stream, nullptr, stats);
 }
 
 int rt_render(const rt_scene *scene, const rt_camera *camera, int32_t max_w, int32_t max_h, uint64_t seed, int32_t device,
@@ -431,7 +597,8 @@ int rt_render(const rt_scene *scene, const rt_camera *camera, int32_t max_w, int
     int rc = check_geometry(camera, max_w, max_h, row_first, row_stride, n_rows);
     if (rc != RT_OK) return rc;
     if (n_rows > 0 && !accum_host) return fail(RT_ERR_INVALID_ARGUMENT, "accum_host is NULL");
-    rc = need_device(device);
+    DeviceGuard guard;
+    rc = guard.enter(device);
     if (rc != RT_OK) return rc;
     const auto t0 = std::chrono::steady_clock::now();
     const size_t npx = (size_t) n_rows * (size_t) (2 * max_w + 1);
@@ -458,6 +625,209 @@ int rt_render(const rt_scene *scene, const rt_camera *camera, int32_t max_w, int
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return rc;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// rt_render_frame: one process, several devices, one gather
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+// librccl.so is loaded on first use (dlopen), so the library itself depends on libamdhip64 only.
+struct RcclApi {
+    typedef int (*init_all_t)(void **, int, const int *);
+    typedef int (*destroy_t)(void *);
+    typedef int (*group_t)(void);
+    typedef int (*send_t)(const void *, size_t, int, int, void *, hipStream_t);
+    typedef int (*recv_t)(void *, size_t, int, int, void *, hipStream_t);
+    typedef const char *(*errstr_t)(int);
+    void *lib = nullptr;
+    init_all_t CommInitAll = nullptr;
+    destroy_t CommDestroy = nullptr;
+    group_t GroupStart = nullptr, GroupEnd = nullptr;
+    send_t Send = nullptr;
+    recv_t Recv = nullptr;
+    errstr_t GetErrorString = nullptr;
+    std::string why;
+    bool ok() const { return lib != nullptr; }
+};
+static RcclApi load_rccl() {
+    RcclApi r;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) { r.why = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "?"); return r; }
+    r.CommInitAll = (RcclApi::init_all_t) dlsym(h, "ncclCommInitAll");
+    r.CommDestroy = (RcclApi::destroy_t) dlsym(h, "ncclCommDestroy");
+    r.GroupStart = (RcclApi::group_t) dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (RcclApi::group_t) dlsym(h, "ncclGroupEnd");
+    r.Send = (RcclApi::send_t) dlsym(h, "ncclSend");
+    r.Recv = (RcclApi::recv_t) dlsym(h, "ncclRecv");
+    r.GetErrorString = (RcclApi::errstr_t) dlsym(h, "ncclGetErrorString");
+    if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.GetErrorString) {
+        r.why = "librccl.so lacks a needed symbol";
+        return r;
+    }
+    r.lib = h;
+    return r;
+}
+static RcclApi &rccl() { static RcclApi api = load_rccl(); return api; }
+#define RT_NCCL_INT32 2 /* ncclInt32 (rccl.h) */
+
+// communicators are expensive to set up (~0.1-1 s): kept per device list for the life of the process
+static std::mutex g_comm_mu;
+static std::map<std::vector<int>, std::vector<void *>> g_comms;
+static int comms_for(const std::vector<int> &devs, std::vector<void *> **out) {
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    auto it = g_comms.find(devs);
+    if (it == g_comms.end()) {
+        std::vector<void *> c(devs.size(), nullptr);
+        const int rc = rccl().CommInitAll(c.data(), (int) devs.size(), devs.data());
+        if (rc != 0) return fail(RT_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(rc));
+        it = g_comms.emplace(devs, c).first;
+    }
+    *out = &it->second;
+    return RT_OK;
+}
+
+struct FrameDevice { // one device's share of a frame; everything is released on every exit path
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int32_t *accum = nullptr; // this device's shard
+    int32_t *stage = nullptr; // on devices[0]: where this device's shard arrives
+    int32_t n_rows = 0;
+    Pending pd;
+    ~FrameDevice() {
+        if (device < 0) return;
+        if (hipSetDevice(device) != hipSuccess) return;
+        pd.release();
+        if (stream) { (void) hipStreamSynchronize(stream); (void) hipStreamDestroy(stream); }
+        (void) hipFree(accum);
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+int rt_render_frame(const rt_scene *scene, const rt_camera *camera, int32_t max_w, int32_t max_h, uint64_t seed, const int32_t *devices,
+                    int32_t n_devices, uint32_t flags, int32_t gather, const rt_render_options *options, int32_t *accum_host, uint8_t *rgb_host,
+                    rt_stats *stats) {
+    if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (!devices || n_devices < 1 || n_devices > 64) return fail(RT_ERR_INVALID_ARGUMENT, "devices: 1 to 64 device ids");
+    if (gather < RT_GATHER_AUTO || gather > RT_GATHER_HOST) return fail(RT_ERR_INVALID_ARGUMENT, "gather must be one of RT_GATHER_*");
+    int rc = check_geometry(camera, max_w, max_h, 0, 1, 2 * max_h + 1);
+    if (rc != RT_OK) return rc;
+    if (!accum_host) return fail(RT_ERR_INVALID_ARGUMENT, "accum_host is NULL");
+    const int visible = visible_devices();
+    if (visible <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible: the render path has no CPU fallback");
+    bool distinct = true;
+    for (int i = 0; i < n_devices; ++i) {
+        if (devices[i] < 0 || devices[i] >= visible) return fail(RT_ERR_INVALID_ARGUMENT, "device index out of range");
+        for (int j = 0; j < i; ++j) distinct = distinct && devices[j] != devices[i];
+    }
+    if (gather == RT_GATHER_RCCL && !distinct) return fail(RT_ERR_INVALID_ARGUMENT, "RT_GATHER_RCCL needs distinct devices (one communicator rank per GPU)");
+    if (gather == RT_GATHER_RCCL && !rccl().ok()) return fail(RT_ERR_UNSUPPORTED, rccl().why);
+    const bool viaSelf = gather == RT_GATHER_RCCL; // asked for by name: devices[0]'s own shard goes through ncclSend/ncclRecv as well
+    if (gather == RT_GATHER_AUTO) gather = (n_devices > 1 && distinct && rccl().ok()) ? RT_GATHER_RCCL : RT_GATHER_PEER;
+
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rows = 2 * max_h + 1, cols = 2 * max_w + 1;
+    const size_t rowBytes = (size_t) cols * 16u;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) { (void) hipGetLastError(); prev = -1; }
+    struct Restore { int prev; ~Restore() { if (prev >= 0) (void) hipSetDevice(prev); } } restore{prev};
+
+    std::vector<FrameDevice> fd((size_t) n_devices); // destroyed (streams drained, buffers freed) before `restore`
+    struct StageOwner { std::vector<int32_t *> bufs; int device; ~StageOwner() { if (hipSetDevice(device) == hipSuccess) for (auto *b : bufs) (void) hipFree(b); } } stages{{}, devices[0]};
+
+    // ---- every device renders its interleaved rows on a stream of its own; nothing waits here ----
+    for (int i = 0; i < n_devices; ++i) {
+        FrameDevice &f = fd[(size_t) i];
+        HIP_TRY(hipSetDevice(devices[i]));
+        f.device = devices[i];
+        f.n_rows = (rows - i + n_devices - 1) / n_devices;
+        if (f.n_rows < 0) f.n_rows = 0;
+        HIP_TRY(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
+        if (f.n_rows > 0) HIP_TRY(hipMalloc((void **) &f.accum, (size_t) f.n_rows * rowBytes));
+        rc = launch_render(scene, camera, max_w, max_h, seed, devices[i], i, n_devices, f.n_rows, flags, f.accum, nullptr, f.stream, options,
+                           stats != nullptr, f.pd);
+        if (rc != RT_OK) return rc;
+    }
+
+    // ---- one gather ----
+    const size_t dpitch = (size_t) n_devices * rowBytes;
+    auto to_host = [&](const int32_t *src, int i, hipStream_t st) -> hipError_t { // de-interleaving strided copy: shard row j -> image row i + j*n
+        if (fd[(size_t) i].n_rows == 0) return hipSuccess;
+        return hipMemcpy2DAsync((char *) accum_host + (size_t) i * rowBytes, dpitch, src, rowBytes, rowBytes, (size_t) fd[(size_t) i].n_rows, hipMemcpyDeviceToHost, st);
+    };
+    if (gather == RT_GATHER_HOST) {
+        for (int i = 0; i < n_devices; ++i) {
+            HIP_TRY(hipSetDevice(devices[i]));
+            HIP_TRY(to_host(fd[(size_t) i].accum, i, fd[(size_t) i].stream));
+        }
+        for (int i = 0; i < n_devices; ++i) { HIP_TRY(hipSetDevice(devices[i])); HIP_TRY(hipStreamSynchronize(fd[(size_t) i].stream)); }
+    } else {
+        HIP_TRY(hipSetDevice(devices[0]));
+        for (int i = 0; i < n_devices; ++i) {
+            int32_t *b = nullptr;
+            if ((i > 0 || viaSelf) && fd[(size_t) i].n_rows > 0) HIP_TRY(hipMalloc((void **) &b, (size_t) fd[(size_t) i].n_rows * rowBytes));
+            stages.bufs.push_back(b);
+            fd[(size_t) i].stage = b;
+        }
+        if (gather == RT_GATHER_PEER) {
+            for (int i = 1; i < n_devices; ++i) {
+                if (fd[(size_t) i].n_rows == 0) continue;
+                HIP_TRY(hipSetDevice(devices[i]));
+                HIP_TRY(hipMemcpyPeerAsync(fd[(size_t) i].stage, devices[0], fd[(size_t) i].accum, devices[i], (size_t) fd[(size_t) i].n_rows * rowBytes, fd[(size_t) i].stream));
+            }
+            for (int i = 1; i < n_devices; ++i) { HIP_TRY(hipSetDevice(devices[i])); HIP_TRY(hipStreamSynchronize(fd[(size_t) i].stream)); }
+        } else { // RCCL over xGMI: every sender on its own render stream, every receive on devices[0]'s
+            std::vector<int> devs(devices, devices + n_devices);
+            std::vector<void *> *comms = nullptr;
+            rc = comms_for(devs, &comms);
+            if (rc != RT_OK) return rc;
+            RcclApi &nc = rccl();
+            int e = nc.GroupStart();
+            for (int i = viaSelf ? 0 : 1; i < n_devices && e == 0; ++i) {
+                const size_t count = (size_t) fd[(size_t) i].n_rows * (size_t) cols * 4u;
+                if (count == 0) continue;
+                HIP_TRY(hipSetDevice(devices[i]));
+                e = nc.Send(fd[(size_t) i].accum, count, RT_NCCL_INT32, 0, (*comms)[(size_t) i], fd[(size_t) i].stream);
+                if (e != 0) break;
+                HIP_TRY(hipSetDevice(devices[0]));
+                e = nc.Recv(fd[(size_t) i].stage, count, RT_NCCL_INT32, i, (*comms)[0], fd[0].stream);
+            }
+            const int e2 = nc.GroupEnd();
+            if (e == 0) e = e2;
+            if (e != 0) return fail(RT_ERR_HIP, std::string("RCCL gather: ") + nc.GetErrorString(e));
+            for (int i = 1; i < n_devices; ++i) { HIP_TRY(hipSetDevice(devices[i])); HIP_TRY(hipStreamSynchronize(fd[(size_t) i].stream)); }
+        }
+        HIP_TRY(hipSetDevice(devices[0]));
+        for (int i = 0; i < n_devices; ++i) HIP_TRY(to_host(fd[(size_t) i].stage ? fd[(size_t) i].stage : fd[(size_t) i].accum, i, fd[0].stream));
+        HIP_TRY(hipStreamSynchronize(fd[0].stream));
+    }
+
+    if (rgb_host) { // PixelStats.mean (Pixel.fs:103-108): integer division of the sums by Count
+        const size_t npx = (size_t) rows * (size_t) cols;
+        for (size_t i = 0; i < npx; ++i) {
+            const int32_t *a = accum_host + i * 4;
+            rgb_host[i * 3 + 0] = (uint8_t) (a[1] / a[0]);
+            rgb_host[i * 3 + 1] = (uint8_t) (a[2] / a[0]);
+            rgb_host[i * 3 + 2] = (uint8_t) (a[3] / a[0]);
+        }
+    }
+    if (stats) {
+        for (int i = 0; i < n_devices; ++i) {
+            HIP_TRY(hipSetDevice(devices[i]));
+            rc = collect_stats(fd[(size_t) i].pd, &stats[i]);
+            if (rc != RT_OK) return rc;
+        }
+        const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        for (int i = 0; i < n_devices; ++i) stats[i].total_ms = total;
+    }
+    return RT_OK;
 }
 
 // ---- output side ------------------------------------------------------------------------------------------
@@ -635,9 +1005,9 @@ __global__ void k_texture(const RenderParams p, int tex, int n, const double *pt
 
 static inline unsigned blocks_for(int n) { return (unsigned) ((n + 255) / 256); }
 
-static int hook_scene_params(int device, const rt_scene *scene, RenderParams &p) {
+static int hook_scene_params(DeviceGuard &guard, int device, const rt_scene *scene, RenderParams &p) {
     if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
-    int rc = need_device(device);
+    int rc = guard.enter(device);
     if (rc != RT_OK) return rc;
     DeviceScene *ds = nullptr;
     rc = device_scene(const_cast<rt_scene *>(scene), device, &ds);
@@ -652,7 +1022,8 @@ extern "C" {
 
 int rt_dev_float_producer(int32_t device, const uint32_t state[4], int32_t n, double *out) {
     if (!state || !out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
-    int rc = need_device(device);
+    DeviceGuard guard;
+    int rc = guard.enter(device);
     if (rc != RT_OK) return rc;
     DevBuf<double> d;
     HIP_TRY(d.alloc((size_t) n));
@@ -666,7 +1037,8 @@ int rt_dev_float_producer(int32_t device, const uint32_t state[4], int32_t n, do
 
 int rt_dev_stream_state(int32_t device, uint64_t seed, int32_t n, const uint64_t *pixel, const uint32_t *sample, uint32_t *state_out) {
     if (!pixel || !sample || !state_out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
-    int rc = need_device(device);
+    DeviceGuard guard;
+    int rc = guard.enter(device);
     if (rc != RT_OK) return rc;
     DevBuf<uint64_t> dp; DevBuf<uint32_t> dsm, dout;
     HIP_TRY(dp.alloc((size_t) n)); HIP_TRY(dsm.alloc((size_t) n)); HIP_TRY(dout.alloc((size_t) n * 4));
@@ -680,7 +1052,8 @@ int rt_dev_stream_state(int32_t device, uint64_t seed, int32_t n, const uint64_t
 
 int rt_dev_bbox_hits(int32_t device, int32_t n, const double *rays, const double *boxes, int32_t *hit_out) {
     if (!rays || !boxes || !hit_out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
-    int rc = need_device(device);
+    DeviceGuard guard;
+    int rc = guard.enter(device);
     if (rc != RT_OK) return rc;
     DevBuf<double> dr, db; DevBuf<int32_t> dh;
     HIP_TRY(dr.alloc((size_t) n * 6)); HIP_TRY(db.alloc((size_t) n * 6)); HIP_TRY(dh.alloc((size_t) n));
@@ -694,7 +1067,8 @@ int rt_dev_bbox_hits(int32_t device, int32_t n, const double *rays, const double
 
 int rt_dev_sphere_first_intersection(int32_t device, int32_t n, const double *rays, const double *spheres, double *t_out) {
     if (!rays || !spheres || !t_out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
-    int rc = need_device(device);
+    DeviceGuard guard;
+    int rc = guard.enter(device);
     if (rc != RT_OK) return rc;
     DevBuf<double> dr, dsph, dt;
     HIP_TRY(dr.alloc((size_t) n * 6)); HIP_TRY(dsph.alloc((size_t) n * 4)); HIP_TRY(dt.alloc((size_t) n));
@@ -708,7 +1082,8 @@ int rt_dev_sphere_first_intersection(int32_t device, int32_t n, const double *ra
 
 int rt_dev_plane_intersection(int32_t device, int32_t n, const double *rays, const double *planes, double *t_out) {
     if (!rays || !planes || !t_out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
-    int rc = need_device(device);
+    DeviceGuard guard;
+    int rc = guard.enter(device);
     if (rc != RT_OK) return rc;
     DevBuf<double> dr, dpl, dt;
     HIP_TRY(dr.alloc((size_t) n * 6)); HIP_TRY(dpl.alloc((size_t) n * 6)); HIP_TRY(dt.alloc((size_t) n));
@@ -722,7 +1097,8 @@ int rt_dev_plane_intersection(int32_t device, int32_t n, const double *rays, con
 
 int rt_dev_pixel_combine(int32_t device, int32_t n, const uint8_t *a, const uint8_t *b, uint8_t *out) {
     if (!a || !b || !out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
-    int rc = need_device(device);
+    DeviceGuard guard;
+    int rc = guard.enter(device);
     if (rc != RT_OK) return rc;
     DevBuf<uint8_t> da, db, dout;
     HIP_TRY(da.alloc((size_t) n * 3)); HIP_TRY(db.alloc((size_t) n * 3)); HIP_TRY(dout.alloc((size_t) n * 3));
@@ -736,7 +1112,8 @@ int rt_dev_pixel_combine(int32_t device, int32_t n, const uint8_t *a, const uint
 
 int rt_dev_pixel_darken(int32_t device, int32_t n, const uint8_t *p, const double *albedo, uint8_t *out) {
     if (!p || !albedo || !out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
-    int rc = need_device(device);
+    DeviceGuard guard;
+    int rc = guard.enter(device);
     if (rc != RT_OK) return rc;
     DevBuf<uint8_t> dp, dout; DevBuf<double> da;
     HIP_TRY(dp.alloc((size_t) n * 3)); HIP_TRY(da.alloc((size_t) n)); HIP_TRY(dout.alloc((size_t) n * 3));
@@ -750,7 +1127,8 @@ int rt_dev_pixel_darken(int32_t device, int32_t n, const uint8_t *p, const doubl
 
 int rt_dev_arith(int32_t device, int32_t op, int32_t n, const double *a, const double *b, double *out) {
     if (!a || !out || n < 0 || op < 0 || op > 6 || (op == 3 && !b)) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
-    int rc = need_device(device);
+    DeviceGuard guard;
+    int rc = guard.enter(device);
     if (rc != RT_OK) return rc;
     DevBuf<double> da, db, dout;
     HIP_TRY(da.alloc((size_t) n)); HIP_TRY(db.alloc(b ? (size_t) n : 0)); HIP_TRY(dout.alloc((size_t) n));
@@ -768,7 +1146,8 @@ int rt_dev_reflection(int32_t device, const rt_scene *scene, int32_t n, const in
     if (!index || !ray_in || !colour_in || !strike || !rng_state || !absorbed || !colour_out || !ray_out || n < 0)
         return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
     RenderParams p;
-    int rc = hook_scene_params(device, scene, p);
+    DeviceGuard guard;
+    int rc = hook_scene_params(guard, device, scene, p);
     if (rc != RT_OK) return rc;
     std::vector<int32_t> obj((size_t) n);
     for (int i = 0; i < n; ++i) {
@@ -789,7 +1168,8 @@ int rt_dev_reflection(int32_t device, const rt_scene *scene, int32_t n, const in
 int rt_dev_hit_object(int32_t device, const rt_scene *scene, int32_t n, const double *rays, int32_t *hit_index, double *strike, uint32_t *counters) {
     if (!rays || !hit_index || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
     RenderParams p;
-    int rc = hook_scene_params(device, scene, p);
+    DeviceGuard guard;
+    int rc = hook_scene_params(guard, device, scene, p);
     if (rc != RT_OK) return rc;
     DevBuf<double> dr, dsk; DevBuf<int32_t> dh; DevBuf<uint32_t> dc;
     HIP_TRY(dr.alloc((size_t) n * 6)); HIP_TRY(dh.alloc((size_t) n)); HIP_TRY(dsk.alloc(strike ? (size_t) n * 3 : 0)); HIP_TRY(dc.alloc(counters ? (size_t) n * 2 : 0));
@@ -807,7 +1187,8 @@ int rt_dev_hit_object(int32_t device, const rt_scene *scene, int32_t n, const do
 int rt_dev_trace_ray(int32_t device, const rt_scene *scene, int32_t bounce_depth, int32_t n, const double *rays, uint32_t *rng_state, uint8_t *colour_out) {
     if (!rays || !rng_state || !colour_out || n < 0 || bounce_depth < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
     RenderParams p;
-    int rc = hook_scene_params(device, scene, p);
+    DeviceGuard guard;
+    int rc = hook_scene_params(guard, device, scene, p);
     if (rc != RT_OK) return rc;
     DevBuf<double> dr; DevBuf<uint32_t> drng; DevBuf<uint8_t> dc;
     HIP_TRY(dr.alloc((size_t) n * 6)); HIP_TRY(drng.alloc((size_t) n * 4)); HIP_TRY(dc.alloc((size_t) n * 3));
@@ -823,7 +1204,8 @@ int rt_dev_texture_colour_at(int32_t device, const rt_scene *scene, int32_t text
     if (!points || !colour_out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
     if (!scene || texture < 0 || (size_t) texture >= scene->host.texRecs.size()) return fail(RT_ERR_INVALID_ARGUMENT, "texture index out of range");
     RenderParams p;
-    int rc = hook_scene_params(device, scene, p);
+    DeviceGuard guard;
+    int rc = hook_scene_params(guard, device, scene, p);
     if (rc != RT_OK) return rc;
     DevBuf<double> dp, duv; DevBuf<uint8_t> dc;
     HIP_TRY(dp.alloc((size_t) n * 3)); HIP_TRY(duv.alloc(uv_out ? (size_t) n * 2 : 0)); HIP_TRY(dc.alloc((size_t) n * 3));

@@ -18,8 +18,15 @@ ap.add_argument("--spp", type=int, default=500)
 ap.add_argument("--depth", type=int, default=50)
 ap.add_argument("--launches", type=int, default=1)
 ap.add_argument("--counters", action="store_true")
+ap.add_argument("--park", type=int, default=0, help="park pool entries per wave; -1 = never park")
+ap.add_argument("--passes", type=int, default=0)
+ap.add_argument("--yield-lanes", type=int, default=0)
+ap.add_argument("--refill-lanes", type=int, default=0)
 a = ap.parse_args()
 rt.set_launch_config(a.block, a.chunk)
+rt.set_park(a.park)
+rt.set_passes(a.passes)
+rt.set_schedule(a.yield_lanes, a.refill_lanes)
 objs, cam, w, h = rt.sample_images.config3_final(spp=a.spp, depth=a.depth, pixels=a.pixels)
 scene = rt.Scene.make(objs)
 rows, cols = 2 * h + 1, 2 * w + 1
@@ -29,7 +36,7 @@ for _ in range(a.launches):
     print({k: st[k] for k in ("kernel_ms", "rays", "aabb_tests", "prim_tests", "samples")}, flush=True)
     if a.counters:
         import ctypes
-        ss = (ctypes.c_uint64 * 9)()
+        ss = (ctypes.c_uint64 * 12)()
         rt.lib.rt_last_stage_stats(ss)
-        names = ("refill_stages", "node_trips", "leaf_stages", "shade_stages", "lanes_refilled", "lanes_shaded")
+        names = ("refill_stages", "node_trips", "leaf_stages", "shade_stages", "lanes_refilled", "lanes_shaded", "wave_ticks", "span_ticks", "waves", "slow_stages", "slow_lanes", "parked_lanes")
         print(dict(zip(names, list(ss))), flush=True)
