@@ -194,24 +194,29 @@ RTD_INLINE double pow5(double x) {
 }
 
 // ---- flattened scene ------------------------------------------------------------------------------------
-// Image layout (bytes; every section 16-byte aligned; built by rt_scene.h, staged verbatim into LDS):
-//   node [n_nodes]   88 B  {hi_x, lo_x, hi_x, hi_y, lo_y, hi_y, hi_z, lo_z, hi_z : double; on_hit, on_miss : int32; 8 B pad}
-//                          Each axis is stored {hi, lo, hi} so that a ray's (near, far) pair is two ADJACENT doubles whichever
-//                          way it travels: +8 for a non-negative inverse direction (lo, hi), +0 for a negative one (hi, lo) --
-//                          one address add and one ds_read2_b64 per axis.  A visit reads 6 of the 9 doubles and the links.
-//                          The pad makes the stride 11 eight-byte LDS slots (odd): lanes sit at unrelated records, and an odd
-//                          stride spreads them over all banks (measured: 80 B 256.0 ms, 88 B 252.9 ms per config-3 frame).
-//                          on_miss = BYTE offset of the node to visit when this box is missed (n_nodes*88 = end);
-//                          on_hit  = byte offset of the next record for a Branch, RTD_LEAF|object index for a Leaf (whose
-//                          successor is on_miss either way).  The LDS copy holds ABSOLUTE LDS addresses in both links
-//                          (patched when the image is staged), so a walk position is used as an address as it is.
-//   geo  [n_obj][3]  d2    sphere {cx,cy}{cz,r^2}{radius,spare} | plane {px,py}{pz,nx}{ny,nz}   48 B/object
+// Image layout (bytes; every section 16-byte aligned; built by rt_scene.h; node, geo and meta are staged verbatim into LDS, mat is
+// read from global memory -- only the general `reflection` of the rarer styles needs it):
+//   node [n_nodes]  112 B  {lo,hi,hi,lo}_x {lo,hi,hi,lo}_y {lo,hi,hi,lo}_z : double; on_hit, on_miss, prim, pad : int32
+//                          Each axis is stored {lo, hi, hi, lo} so that a ray's (near, far) pair is ONE aligned 16-byte read
+//                          whichever way it travels: +0 for a non-negative inverse direction (lo, hi), +16 for a negative one
+//                          (hi, lo) -- one address add and one ds_read_b128 per axis.  (ds_read_b128 moves 256 B per LDS clock,
+//                          the ds_read2_b64 of the earlier {hi,lo,hi} layout 128: with 16 waves per CU in the node loop the LDS
+//                          array was busy 64 % of the frame.)  A visit reads 6 of the 12 doubles and the links.
+//                          on_miss = BYTE offset of the node to visit when this box is missed (n_nodes*112 = end);
+//                          on_hit  = byte offset of the next record for a Branch, RTD_LEAF | the record's OWN offset for a
+//                          Leaf: a walk that hits a leaf box stops there with the flag set, and the leaf test reads the
+//                          sphere's index (prim) and where to go on (on_miss) from the record itself -- so a walk carries
+//                          one position and nothing else.  prim = object index of a Leaf, -1 for a Branch.  The LDS copy
+//                          holds ABSOLUTE LDS addresses in both links (patched when the image is staged), so a walk
+//                          position is used as an address as it is.
+//   geo  [n_obj][3]  d2    sphere {cx,cy}{cz,r^2}{albedo,spare} | plane {px,py}{pz,nx}{ny,nz}   48 B/object
 //   meta [n_obj]     i2    {kind|style<<2|flipped<<5, rgb|(texture+1)<<24}                   8 B/object
-//   mat  [n_obj][4]  double {albedo, fuzz|ior, prob, 1/ior} (Dielectric) | {albedo, ior, 1/ior, schlickOutside} (Glass, whose
-//                          schlickInside sits in the sphere record's spare double): per-material values of Sphere.fs:117,283-289   32 B/object
+//   mat  [n_obj][4]  double sphere {radius, fuzz|ior, prob, 1/ior} (Dielectric) | {radius, ior, 1/ior, schlickOutside} (Glass, whose
+//                          schlickInside sits in the sphere record's spare double): per-material values of Sphere.fs:117,283-289;
+//                          plane {albedo, fuzz, 0, 0}                                         32 B/object, global memory
 // Objects: bounded spheres first (tree leaves point at them), then the unbounded list in Scene.make order.
 #ifndef RTD_NODE_BYTES
-#define RTD_NODE_BYTES 88
+#define RTD_NODE_BYTES 112
 #endif
 #define RTD_LEAF 0x40000000 /* flag in on_hit / in a walk offset: a leaf's primitive test is pending */
 struct TexRec { // global memory only
@@ -230,12 +235,14 @@ template <> struct Ptrs<true> {
     typedef const RTD_AS3 unsigned char *bp;
     typedef const RTD_AS3 d2 *d2p;
     typedef const RTD_AS3 i2 *i2p;
+    typedef const RTD_AS3 int *ip;
     typedef const RTD_AS3 double *dp;
 };
 template <> struct Ptrs<false> {
     typedef const unsigned char *bp;
     typedef const d2 *d2p;
     typedef const i2 *i2p;
+    typedef const int *ip;
     typedef const double *dp;
 };
 
@@ -243,7 +250,7 @@ template <bool LDS> struct SceneView {
     typename Ptrs<LDS>::bp node;
     typename Ptrs<LDS>::d2p geo;
     typename Ptrs<LDS>::i2p meta;
-    typename Ptrs<LDS>::dp mat;
+    const double *mat; // global memory in both variants
     int n_nodes, n_bounded, n_unbounded;
     int first, end; // walk positions of the root record and of "tree exhausted" (LDS: absolute addresses; else offsets from `node`)
     const TexRec *tex;
@@ -252,6 +259,7 @@ template <bool LDS> struct SceneView {
 
 struct SceneOffsets { // byte offsets into the image
     uint32_t node, geo, meta, mat, total;
+    uint32_t lds_total; // node + geo + meta: what the LDS variant of the kernel stages
     int32_t n_nodes, n_bounded, n_unbounded;
 };
 
@@ -329,54 +337,113 @@ RTD_INLINE double plane_intersection(V3 o, V3 d, V3 p0, V3 n) {
 // strict-`<` tie-breaking of Scene.fs:45-47 is unchanged.
 struct Walk {
     int off;        // position of the next node record (SceneView::first ..); >= SceneView::end when the tree is exhausted or the lane is not walking;
-                    // RTD_LEAF|object while that leaf's primitive test is pending (then `resume` is where the walk continues)
-    int resume;
+                    // RTD_LEAF|position of a Leaf record while that leaf's primitive test is pending
     int best;       // bestObject (object index) or -1
     double bestLen; // bestLength; NaN until something is hit (Scene.fs:64)
 };
 struct WalkCtx {
     double ix, iy, iz; // BoundingBox.inverseDirections (BoundingBox.fs:25-28)
-    int nX, nY, nZ;    // 0 or 8: byte offset of each axis' (near, far) pair inside its {hi, lo, hi} triple: the swap of BoundingBox.fs:52-55
+    int nX, nY, nZ;    // 0 or 16: byte offset of each axis' (near, far) pair inside its {lo, hi, hi, lo} quad: the swap of BoundingBox.fs:52-55
     double bestF;      // bestFloat = bestLength^2, +inf until something is hit (Scene.fs:65)
 };
-RTD_INLINE void walk_begin(Walk &w, int first) { w.off = first; w.resume = first; w.best = -1; w.bestLen = __builtin_nan(""); }
+RTD_INLINE void walk_begin(Walk &w, int first) { w.off = first; w.best = -1; w.bestLen = __builtin_nan(""); }
 RTD_INLINE WalkCtx walk_ctx(V3 d, const Walk &w) {
     WalkCtx c;
     c.ix = 1.0 / d.x; c.iy = 1.0 / d.y; c.iz = 1.0 / d.z;
-    c.nX = c.ix < 0.0 ? 0 : 8; c.nY = c.iy < 0.0 ? 0 : 8; c.nZ = c.iz < 0.0 ? 0 : 8;
+    c.nX = c.ix < 0.0 ? 16 : 0; c.nY = c.iy < 0.0 ? 16 : 0; c.nZ = c.iz < 0.0 ? 16 : 0;
     c.bestF = (w.best < 0) ? __builtin_inf() : w.bestLen * w.bestLen; // `a = point * point` (Scene.fs:45), recomputed
     return c;
 }
 template <bool LDS> RTD_INLINE typename Ptrs<LDS>::bp node_at(const SceneView<LDS> &sc, int pos);
 template <> RTD_INLINE Ptrs<true>::bp node_at<true>(const SceneView<true> &, int pos) { return (Ptrs<true>::bp) (uintptr_t) (uint32_t) pos; }
 template <> RTD_INLINE Ptrs<false>::bp node_at<false>(const SceneView<false> &sc, int pos) { return sc.node + pos; }
-// One BoundingBox.hits + advance: w.off becomes on_hit or on_miss; a hit Leaf leaves RTD_LEAF|object there.
+// One BoundingBox.hits + advance: w.off becomes on_hit or on_miss; a hit Leaf leaves RTD_LEAF|its own position there.
 template <bool LDS>
 RTD_INLINE void node_step(const SceneView<LDS> &sc, V3 o, const WalkCtx &c, Walk &w) {
     typedef typename Ptrs<LDS>::bp bp;
-    typedef typename Ptrs<LDS>::dp dp;
     typedef typename Ptrs<LDS>::i2p i2p;
     bp rec = node_at<LDS>(sc, w.off);
-    bp ax = rec + c.nX, ay = rec + c.nY, az = rec + c.nZ;
-    const double vnx = *(dp) (ax), vfx = *(dp) (ax + 8);
-    const double vny = *(dp) (ay + 24), vfy = *(dp) (ay + 32);
-    const double vnz = *(dp) (az + 48), vfz = *(dp) (az + 56);
-    const i2 lk = *(i2p) (rec + 72);
+    typedef typename Ptrs<LDS>::d2p d2p;
+    const d2 vx = *(d2p) (rec + c.nX), vy = *(d2p) (rec + 32 + c.nY), vz = *(d2p) (rec + 64 + c.nZ);
+    const double vnx = vx.x, vfx = vx.y, vny = vy.x, vfy = vy.y, vnz = vz.x, vfz = vz.y;
+    const i2 lk = *(i2p) (rec + 96);
     const bool hit = bbox_hits_nf(c.ix, c.iy, c.iz, o, vnx, vfx, vny, vfy, vnz, vfz);
     w.off = hit ? lk.x : lk.y;
-    w.resume = lk.y;
+}
+// The node loop of the LDS-resident scene, as one block of assembly: node_step for every lane with off < end, again and again
+// until at most `stop` lanes are still walking.  The instructions are those the compiler makes of node_step + bbox_hits_nf
+// (same operations, same operand order, hence the same bits); what the compiler could not be talked into is ONE loop-carried
+// register (the walk position) with no copies of it -- the compiled loop shuffled it through five to eight v_mov per trip
+// (1.8e9 trips per bench frame).  v[100:113] hold the three (near, far) pairs and the link pair (the halves of a 128-bit
+// operand cannot be named through an asm operand, so these are fixed registers, declared as clobbers).
+// Lanes at >= end (finished, pending leaf, idle) are masked off; exec is restored before the block ends.
+RTD_INLINE int node_loop_lds(int off, int end, int stop, V3 o, const WalkCtx &c) {
+    int ax, ay, az, cnt;
+    unsigned long long save, save2;
+    const double inf = __builtin_inf();
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n"
+        "1:\n"
+        "  v_cmp_gt_i32 vcc, %[end], %[off]\n"
+        "  s_bcnt1_i32_b64 %[cnt], vcc\n"
+        "  s_cmp_le_u32 %[cnt], %[stop]\n"
+        "  s_cbranch_scc1 2f\n"
+        "  s_and_saveexec_b64 %[save], vcc\n"
+        "  v_add_u32 %[ax], %[off], %[nx]\n"
+        "  v_add_u32 %[ay], %[off], %[ny]\n"
+        "  v_add_u32 %[az], %[off], %[nz]\n"
+        "  ds_read_b128 v[100:103], %[ax]\n"
+        "  ds_read_b128 v[104:107], %[ay] offset:32\n"
+        "  ds_read_b128 v[108:111], %[az] offset:64\n"
+        "  ds_read_b64 v[112:113], %[off] offset:96\n"
+        "  s_waitcnt lgkmcnt(3)\n"
+        "  v_add_f64 v[100:101], v[100:101], -%[ox]\n"
+        "  v_mul_f64 v[100:101], %[ix], v[100:101]\n"
+        "  v_add_f64 v[102:103], v[102:103], -%[ox]\n"
+        "  v_max_f64 v[100:101], v[100:101], 0\n"
+        "  v_mul_f64 v[102:103], %[ix], v[102:103]\n"
+        "  v_min_f64 v[102:103], v[102:103], %[inf]\n"
+        "  s_waitcnt lgkmcnt(2)\n"
+        "  v_add_f64 v[104:105], v[104:105], -%[oy]\n"
+        "  v_mul_f64 v[104:105], %[iy], v[104:105]\n"
+        "  v_max_f64 v[100:101], v[104:105], v[100:101]\n"
+        "  v_add_f64 v[106:107], v[106:107], -%[oy]\n"
+        "  v_mul_f64 v[106:107], %[iy], v[106:107]\n"
+        "  v_min_f64 v[102:103], v[106:107], v[102:103]\n"
+        "  s_waitcnt lgkmcnt(1)\n"
+        "  v_add_f64 v[108:109], v[108:109], -%[oz]\n"
+        "  v_mul_f64 v[108:109], %[iz], v[108:109]\n"
+        "  v_max_f64 v[100:101], v[108:109], v[100:101]\n"
+        "  v_add_f64 v[110:111], v[110:111], -%[oz]\n"
+        "  v_mul_f64 v[110:111], %[iz], v[110:111]\n"
+        "  v_cmp_lt_f64 vcc, 0, v[102:103]\n"
+        "  v_min_f64 v[102:103], v[110:111], v[102:103]\n"
+        "  v_cmp_ge_f64 %[save2], v[102:103], v[100:101]\n"
+        "  s_and_b64 vcc, vcc, %[save2]\n"
+        "  s_waitcnt lgkmcnt(0)\n"
+        "  v_cndmask_b32 %[off], v113, v112, vcc\n"
+        "  s_mov_b64 exec, %[save]\n"
+        "  s_branch 1b\n"
+        "2:\n"
+        : [off] "+v"(off), [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [cnt] "=&s"(cnt), [save] "=&s"(save), [save2] "=&s"(save2)
+        : [end] "s"(end), [stop] "s"(stop), [nx] "v"(c.nX), [ny] "v"(c.nY), [nz] "v"(c.nZ), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z),
+          [ix] "v"(c.ix), [iy] "v"(c.iy), [iz] "v"(c.iz), [inf] "s"(inf)
+        : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113");
+    return off;
 }
 // Leaf: Hittable.hits (Hittable.fs:27-31) -> Sphere.firstIntersection, kept if t^2 < bestFloat (strict; NaN fails).
 // On an exact tie the reference keeps the leaf its depth-first walk met first; object indices are those ranks (rt_scene.h),
 // so the second clause reproduces that when the walked tree visits leaves in another order (and never fires when it does not).
 template <bool LDS>
 RTD_INLINE void leaf_test(const SceneView<LDS> &sc, V3 o, V3 d, WalkCtx &c, Walk &w) {
-    const int prim = w.off & (RTD_LEAF - 1);
+    typedef typename Ptrs<LDS>::bp bp;
+    bp rec = node_at<LDS>(sc, w.off & (RTD_LEAF - 1));
+    const int next = *(typename Ptrs<LDS>::ip) (rec + 100), prim = *(typename Ptrs<LDS>::ip) (rec + 104); // on_miss, prim
     const d2 g0 = sc.geo[prim * 3 + 0], g1 = sc.geo[prim * 3 + 1];
     const double t = sphere_first_intersection(o, d, mk(g0.x, g0.y, g1.x), g1.y);
     const double a = t * t;
     if (a < c.bestF || (a == c.bestF && prim < w.best)) { c.bestF = a; w.best = prim; w.bestLen = t; }
-    w.off = w.resume;
+    w.off = next;
 }
 // UnboundedObjects, in array order, accepted only when Float.compare a bestFloat = Less (Scene.fs:77-86)
 template <bool LDS, bool COUNT>
@@ -478,7 +545,8 @@ RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, 
     const bool isPlane = (m.x & 3) == (int) RTD_KIND_PLANE;
     const int style = (m.x >> 2) & 7;
     const d2 g0 = sc.geo[obj * 3 + 0], g1 = sc.geo[obj * 3 + 1], g2 = sc.geo[obj * 3 + 2];
-    const double albedo = sc.mat[obj * 4 + 0], p1 = sc.mat[obj * 4 + 1], p2 = sc.mat[obj * 4 + 2], p3 = sc.mat[obj * 4 + 3];
+    const double m0 = sc.mat[obj * 4 + 0], p1 = sc.mat[obj * 4 + 1], p2 = sc.mat[obj * 4 + 2], p3 = sc.mat[obj * 4 + 3];
+    const double albedo = isPlane ? m0 : g2.x; // a sphere's albedo rides in its geo record (the common Lambert case never reads `mat`)
     uint32_t texColour = (uint32_t) m.y & 0x00FFFFFFu;
     const int texId = (int) (((uint32_t) m.y) >> 24) - 1;
     // Styles that carry a Texture: every SphereStyle but LightSourceCap (Sphere.fs:10-37), and the plane LightSource
@@ -503,7 +571,7 @@ RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, 
         else act = ACT_LAMBERT_ONCE;
     } else {
         const V3 c = mk(g0.x, g0.y, g1.x);
-        const double r2 = g1.y, radius = g2.x;
+        const double r2 = g1.y, radius = m0;
         const bool flipped = (m.x >> 5) & 1; // Float.compare radius 0.0 = Less (Sphere.fs:321), set by the host
         if (!unitise(vsub(strike, c), n)) n = mk(0.0, 0.0, 0.0); // Sphere.normal (Sphere.fs:65-66)
         V3 co = vsub(c, o);
@@ -617,7 +685,7 @@ RTD_INLINE bool reflection_fast(const SceneView<LDS> &sc, int obj, i2 m, V3 stri
     const uint32_t texColour = (uint32_t) m.y & 0x00FFFFFFu;
     if ((((uint32_t) m.x >> 2) & 7u) == 0u) { colour = pix_combine(colour, texColour); return true; } // LightSource, sphere or plane
     const d2 g0 = sc.geo[obj * 3 + 0], g1 = sc.geo[obj * 3 + 1];
-    const double albedo = sc.mat[obj * 4 + 0];
+    const double albedo = sc.geo[obj * 3 + 2].x;
     const V3 c = mk(g0.x, g0.y, g1.x);
     const double r2 = g1.y;
     const bool flipped = (m.x >> 5) & 1;

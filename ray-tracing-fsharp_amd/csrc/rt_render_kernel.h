@@ -86,7 +86,7 @@ template <> RTD_INLINE SceneView<true> make_view<true>(const RenderParams &p, co
     v.node = (Ptrs<true>::bp) (b + p.off.node);
     v.geo = (Ptrs<true>::d2p) (b + p.off.geo);
     v.meta = (Ptrs<true>::i2p) (b + p.off.meta);
-    v.mat = (Ptrs<true>::dp) (b + p.off.mat);
+    v.mat = (const double *) (p.scene_image + p.off.mat);
     v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
     v.first = (int) (uint32_t) (uintptr_t) v.node; v.end = v.first + v.n_nodes * RTD_NODE_BYTES; // links were made absolute at staging
     v.tex = p.tex; v.texels = p.texels;
@@ -248,6 +248,8 @@ struct Sched {
         WalkCtx c = walk_ctx(d, w); // cheap to re-derive; keeps 9 doubles out of the parked state
         const int stop = (nBusy - p.yield_lanes) > 0 ? (nBusy - p.yield_lanes) : 0; // active <= stop  <=>  waiting >= yield
         for (;;) {
+            if constexpr (LDS && !COUNT) w.off = node_loop_lds(w.off, end, stop, o, c);
+            else
             for (;;) {
                 const bool act = w.off < end;
                 const int nAct = __popcll(__builtin_amdgcn_ballot_w64(act));
@@ -512,7 +514,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
 
     uint32_t sceneBytes = 0;
     if (LDS) { // stage the scene image: 16 B per lane per trip, coalesced
-        sceneBytes = p.off.total;
+        sceneBytes = p.off.lds_total;
         const d2 *src = (const d2 *) p.scene_image;
         RTD_AS3 d2 *dst = (RTD_AS3 d2 *) smem;
         for (uint32_t i = threadIdx.x; i < sceneBytes / 16u; i += BLOCK) dst[i] = src[i];
@@ -522,9 +524,9 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     if (LDS) { // make the links absolute LDS addresses: a walk position then IS the record's address (no add per visit)
         RTD_AS3 unsigned char *nodes = (RTD_AS3 unsigned char *) smem + p.off.node;
         for (int i = threadIdx.x; i < p.off.n_nodes; i += BLOCK) {
-            RTD_AS3 i2 *lk = (RTD_AS3 i2 *) (nodes + i * RTD_NODE_BYTES + 72);
+            RTD_AS3 i2 *lk = (RTD_AS3 i2 *) (nodes + i * RTD_NODE_BYTES + 96);
             i2 v = *lk;
-            if (!(v.x & RTD_LEAF)) v.x += sc.first;
+            v.x += sc.first; // a Leaf's RTD_LEAF flag (bit 30) is above every LDS address and survives the add
             v.y += sc.first;
             *lk = v;
         }

@@ -272,7 +272,7 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
     }
     const size_t nb = bounded.size(), nu = unbounded.size(), nobj = nb + nu;
     // walk offsets are int32 byte offsets with bit 30 reserved for the pending-leaf flag (RTD_LEAF)
-    if (nb > 6000000u || nobj > 16000000u) { status = RT_ERR_UNSUPPORTED; return "scene too large for 32-bit walk offsets (6,000,000 bounded spheres)"; } // (2n-1) * 88 B < 2^30
+    if (nb > 4500000u || nobj > 16000000u) { status = RT_ERR_UNSUPPORTED; return "scene too large for 32-bit walk offsets (4,500,000 bounded spheres)"; } // (2n-1) * 112 B < 2^30 (bit 30 = RTD_LEAF)
     // ---- Sphere.make's box (Sphere.fs:333-336): centre + (-r,-r,-r) .. centre + (r,r,r); inverted when r < 0 ----
     std::vector<Box> boxes(nb); // by position in `bounded` (input order), which is what BoundingBoxTree.make receives
     bool finite = true;
@@ -319,22 +319,26 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
     off.node = (uint32_t) cur; cur = align16(cur + nn * RTD_NODE_BYTES);
     off.geo = (uint32_t) cur;  cur = align16(cur + nobj * 48u);
     off.meta = (uint32_t) cur; cur = align16(cur + nobj * 8u);
+    off.lds_total = (uint32_t) cur; // what follows stays in global memory
     off.mat = (uint32_t) cur;  cur = align16(cur + nobj * 32u);
     off.total = (uint32_t) cur;
     off.n_nodes = (int32_t) nn; off.n_bounded = (int32_t) nb; off.n_unbounded = (int32_t) nu;
     s.image.assign(cur == 0 ? 16 : cur, 0);
     if (cur == 0) off.total = 16;
+    if (off.lds_total == 0) off.lds_total = 16;
     unsigned char *pnode = s.image.data() + off.node;
     double *pgeo = (double *) (s.image.data() + off.geo);
     int32_t *pmeta = (int32_t *) (s.image.data() + off.meta);
     double *pmat = (double *) (s.image.data() + off.mat);
     for (size_t i = 0; i < nn; ++i) {
         double *bx = (double *) (pnode + i * RTD_NODE_BYTES);
-        int32_t *lk = (int32_t *) (pnode + i * RTD_NODE_BYTES + 72);
-        for (int a = 0; a < 3; ++a) { bx[a * 3] = wt.box[i].mx[a]; bx[a * 3 + 1] = wt.box[i].mn[a]; bx[a * 3 + 2] = wt.box[i].mx[a]; }
+        int32_t *lk = (int32_t *) (pnode + i * RTD_NODE_BYTES + 96);
+        for (int a = 0; a < 3; ++a) { bx[a * 4] = wt.box[i].mn[a]; bx[a * 4 + 1] = wt.box[i].mx[a]; bx[a * 4 + 2] = wt.box[i].mx[a]; bx[a * 4 + 3] = wt.box[i].mn[a]; }
         const int32_t onMiss = wt.skip[i] * RTD_NODE_BYTES; // byte offset of the record to visit on a miss
-        lk[0] = wt.prim[i] >= 0 ? (int32_t) (RTD_LEAF | wt.prim[i]) : (int32_t) ((i + 1) * RTD_NODE_BYTES); // on_hit
+        lk[0] = wt.prim[i] >= 0 ? (int32_t) (RTD_LEAF | (i * RTD_NODE_BYTES)) : (int32_t) ((i + 1) * RTD_NODE_BYTES); // on_hit
         lk[1] = onMiss;
+        lk[2] = wt.prim[i]; // object index of a Leaf, -1 for a Branch
+        lk[3] = 0;
     }
     for (size_t j = 0; j < nobj; ++j) {
         const rt_hittable &o = h[(size_t) s.objToOrig[j]];
@@ -348,12 +352,12 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
         } else {
             g[0] = o.point[0]; g[1] = o.point[1]; g[2] = o.point[2];
             g[3] = o.radius * o.radius; // RadiusSquared (Sphere.fs:326)
-            g[4] = o.radius; g[5] = 0.0;
+            g[4] = o.albedo; g[5] = 0.0; // the radius itself (LightSourceCap only) is in `mat`
             // flipped = Float.compare this.Radius 0.0 = Less (Sphere.fs:321)
             const bool flipped = !(std::fabs(o.radius - 0.0) < 0.00000001) && (o.radius < 0.0);
             m0 = RTD_KIND_SPHERE | (o.style << 2) | (flipped ? 32u : 0u);
             const bool usesIor = o.style == RT_SPHERE_DIELECTRIC || o.style == RT_SPHERE_GLASS;
-            pmat[j * 4 + 0] = o.albedo; pmat[j * 4 + 1] = usesIor ? o.ior : o.fuzz; pmat[j * 4 + 2] = o.prob; pmat[j * 4 + 3] = 0.0;
+            pmat[j * 4 + 0] = o.radius; pmat[j * 4 + 1] = usesIor ? o.ior : o.fuzz; pmat[j * 4 + 2] = o.prob; pmat[j * 4 + 3] = 0.0;
             if (usesIor) {
                 // Per-material values the reference recomputes at every hit from the same inputs with the same IEEE operations
                 // (this translation unit is built with -ffp-contract=off): `1.0 / ior` (Sphere.fs:117, 283-284) and Schlick's

@@ -139,7 +139,7 @@ static const char *check_settings(const Settings &s) {
     return nullptr;
 }
 static size_t lds_need(const rth::HostScene &h, bool lds, int block, int chunk) {
-    return (lds ? (size_t) h.off.total : 0u) + (size_t) (block / 64) * RTD_WAVE_WORDS(chunk) * 4u;
+    return (lds ? (size_t) h.off.lds_total : 0u) + (size_t) (block / 64) * RTD_WAVE_WORDS(chunk) * 4u;
 }
 struct LaunchPlan {
     int block = 1024, chunk = 16, park = 0;

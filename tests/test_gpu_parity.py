@@ -229,8 +229,13 @@ def test_trace_ray_paths(rt, orc):
 
 # ---- whole renders ------------------------------------------------------------------------------------------------
 def _render_both(rt, orc, objs, cam, w, h, seed, **shard):
+    """The HIP render (the counting kernel variant, and -- asserted equal to it -- the plain variant the bench times, whose
+    node loop is hand-written assembly) and the oracle's."""
     s, o = _scene_pair(rt, orc, objs)
     res = s.render_rows(w, h, cam, seed=seed, counters=True, **shard)
+    plain = s.render_rows(w, h, cam, seed=seed, counters=False, **shard)
+    assert np.array_equal(plain.accum, res.accum) and np.array_equal(plain.rgb, res.rgb), "kernel variants disagree"
+    assert plain.stats["samples"] == res.stats["samples"] and plain.stats["pixels_early"] == res.stats["pixels_early"]
     acc, rgb, st = o.render_rows(w, h, cam.to_abi(), seed=seed, threads=8, **shard)
     return res, acc, rgb, st
 
