@@ -298,8 +298,8 @@ int rt_set_park(int32_t park_lanes);
 /* Diagnostic: wave-level stage executions of the calling THREAD's last render that asked for stats with
  * RT_RENDER_COUNTERS set: {refill stages, node-loop trips, leaf stages, shade stages, lanes refilled, lanes shaded, sum of
  * wave lifetimes and first-start-to-last-end span (both in 100 MHz ticks), waves launched, general-reflection stages, lanes in them,
- * lanes parked}. */
-int rt_last_stage_stats(uint64_t out[12]);
+ * lanes parked, shader-clock cycles summed over the waves inside the refill / general-reflection / walk / shade stages}. */
+int rt_last_stage_stats(uint64_t out[16]);
 
 /*
  * ---- Device unit hooks ---------------------------------------------------------------------------
@@ -338,7 +338,9 @@ int rt_dev_texture_colour_at(int32_t device, const rt_scene *scene, int32_t text
                              double *uv_out, uint8_t *colour_out);
 /* IEEE-754 conformance probes of the device arithmetic the path relies on: op 0: 1.0/x, 1: sqrt(x), 2: rint(x),
  * 3: x/y, 4: pow5(x) = Math.Pow(x, 5.0) (Sphere.fs:290), 5: the path's sqrt for operands > 1e-8, 6: its 1.0/sqrt(x) for
- * operands >= 1e-8 (both must equal the correctly rounded results). a,b: n doubles (b may be NULL for unary ops). */
+ * operands >= 1e-8 (both must equal the correctly rounded results), 7: Math.Acos(x), 8: Math.Sin(x), 9: Math.Atan2(x, y) as the
+ * texture maps use them (Sphere.fs:59-60, Texture.fs:58): the correctly rounded values (csrc/rt_trig.h).
+ * a,b: n doubles (b may be NULL for unary ops). */
 int rt_dev_arith(int32_t device, int32_t op, int32_t n, const double *a, const double *b, double *out);
 
 #ifdef __cplusplus

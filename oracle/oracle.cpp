@@ -26,6 +26,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <quadmath.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -369,11 +370,20 @@ struct TextureTable {
     std::vector<std::vector<uint8_t>> texels; // per texture (IMAGE only)
 };
 
+// Math.Acos / Math.Atan2 / Math.Sin (Sphere.fs:59-60, Texture.fs:58) are the platform's C runtime in .NET; libms agree with each
+// other only to an ulp or so, and one ulp of (u, v) flips a truncating texel index.  The oracle takes the platform-independent
+// value those approximate: the exact result rounded once, computed here in binary128 (libquadmath, ~113 bits) and rounded to
+// double -- deliberately a different route from the HIP path's double-double Newton step (csrc/rt_trig.h).  glibc's results are
+// within 1 ulp of these (tests/test_trig_cr.py, which also pins both routes to mpmath at 200 bits).
+static inline double crAcos(double x) { return (double) acosq((__float128) x); }
+static inline double crAtan2(double y, double x) { return (double) atan2q((__float128) y, (__float128) x); }
+static inline double crSin(double x) { return (double) sinq((__float128) x); }
+
 // Sphere.planeMapInverse (Sphere.fs:55-61)
 static inline void planeMapInverse(double radius, Point centre, Point p, double &outPhi, double &outTheta) {
     Vector v = Vec::scale(1.0 / radius, Pt::differenceToThenFrom(p, centre));
-    double theta = std::acos(-v.y);
-    double phi = std::atan2(-v.z, v.x) + M_PI;
+    double theta = crAcos(-v.y);
+    double phi = crAtan2(-v.z, v.x) + M_PI;
     outPhi = (phi / (2.0 * M_PI));
     outTheta = theta / M_PI;
 }
@@ -402,7 +412,7 @@ static Pixel paramColourAt(const TextureTable &tt, int id, double x, double y) {
         return Pixel{c[0], c[1], c[2]};
     }
     case RT_TEXTURE_CHECKERED: { // Texture.fs:56-62
-        double sine = std::sin(t.grid_size * x) * std::sin(t.grid_size * y);
+        double sine = crSin(t.grid_size * x) * crSin(t.grid_size * y);
         if (Float::compare(sine, 0.0) == Comparison::Less) return paramColourAt(tt, t.even, x, y);
         return paramColourAt(tt, t.odd, x, y);
     }
@@ -1425,6 +1435,12 @@ int orc_arith(int32_t op, int32_t n, const double *a, const double *b, double *o
         case 3: out[i] = a[i] / b[i]; break;
         case 4: out[i] = SphereM::pow5(a[i]); break;
         case 5: out[i] = std::pow(a[i], 5.0); break; // the C runtime's pow, for comparison
+        case 7: out[i] = crAcos(a[i]); break;
+        case 8: out[i] = crSin(a[i]); break;
+        case 9: out[i] = crAtan2(a[i], b[i]); break;
+        case 10: out[i] = std::acos(a[i]); break; // the C runtime's, for comparison
+        case 11: out[i] = std::sin(a[i]); break;
+        case 12: out[i] = std::atan2(a[i], b[i]); break;
         default: g_err = "bad op"; return RT_ERR_INVALID_ARGUMENT;
         }
     }

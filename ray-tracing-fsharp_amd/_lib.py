@@ -64,7 +64,7 @@ SIGNATURES = {
     "rt_set_passes": (C.c_int, [C.c_int32]),
     "rt_set_walk_tree": (C.c_int, [C.c_int32]),
     "rt_set_park": (C.c_int, [C.c_int32]),
-    "rt_last_stage_stats": (C.c_int, [_u64p]),  # out[12]
+    "rt_last_stage_stats": (C.c_int, [_u64p]),  # out[16]
     "rt_camera_make_basic": (C.c_int, [C.c_int32, C.c_double, C.c_double, _dp, _dp, _dp, _P(A.rt_camera)]),
     "rt_scene_create": (C.c_int, [_P(A.rt_hittable), C.c_size_t, _P(A.rt_texture), C.c_size_t, _P(C.c_void_p)]),
     "rt_scene_create_ex": (C.c_int, [_P(A.rt_hittable), C.c_size_t, _P(A.rt_texture), C.c_size_t, _P(A.rt_scene_options), _P(C.c_void_p)]),

@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "rt_trig.h"
+
 #pragma clang fp contract(off)
 
 namespace rtd {
@@ -490,15 +492,15 @@ RTD_INLINE int hit_object(const SceneView<LDS> &sc, V3 o, V3 d, double &bestLen,
 }
 
 // ---- Textures (Texture.fs:50-67, Sphere.planeMapInverse Sphere.fs:55-61) --------------------------------------------
-// Rare (only textured spheres), transcendental-heavy: kept out of line so the common path stays small.
+// Rare (only textured spheres), transcendental-heavy (double-double arithmetic, rt_trig.h): kept out of line so the common path stays small.
 __device__ __noinline__ uint32_t texture_colour_at(const TexRec *tex, const uint8_t *texels, int id, V3 p, double *uv) {
     const TexRec root = tex[id];
     if (root.kind == 0u) return root.rgb; // ParameterisedTexture.toTexture's Colour case (Texture.fs:71)
     double inv = 1.0 / root.map_radius;
     V3 v = vscale(inv, vsub(p, mk(root.cx, root.cy, root.cz)));
     const double PI = 3.14159265358979323846;
-    double theta = acos(-v.y);
-    double phi = atan2(-v.z, v.x) + PI;
+    double theta = rtt::cr_acos(-v.y);           // Math.Acos / Math.Atan2 / Math.Sin: the correctly rounded values (rt_trig.h)
+    double phi = rtt::cr_atan2(-v.z, v.x) + PI;
     double x = (phi / (2.0 * PI));
     double y = theta / PI;
     if (uv) { uv[0] = x; uv[1] = y; }
@@ -506,7 +508,7 @@ __device__ __noinline__ uint32_t texture_colour_at(const TexRec *tex, const uint
     for (int depth = 0; depth < 16; ++depth) { // Checkered trees descend to strictly smaller indices
         const TexRec t = tex[cur];
         if (t.kind == 1u) { // Checkered (Texture.fs:56-62)
-            double sine = sin(t.grid * x) * sin(t.grid * y);
+            double sine = rtt::cr_sin(t.grid * x) * rtt::cr_sin(t.grid * y);
             cur = (fcmp(sine, 0.0) == CMP_LT) ? t.even : t.odd;
             continue;
         }

@@ -105,7 +105,10 @@ template <> RTD_INLINE SceneView<false> make_view<false>(const RenderParams &p, 
     return v;
 }
 
-struct StageStats { uint32_t refill, trips, leaf, shade, refillLanes, shadeLanes, slow, slowLanes, parkedLanes; }; // wave-uniform, COUNT variant only
+struct StageStats { // wave-uniform, COUNT variant only
+    uint32_t refill, trips, leaf, shade, refillLanes, shadeLanes, slow, slowLanes, parkedLanes;
+    unsigned long long tRefill, tSlow, tWalk, tShade; // shader-clock cycles this wave spent inside each stage (s_memtime)
+};
 
 #define RTD_YIELD_DEFAULT 44
 #define RTD_REFILL_DEFAULT 12
@@ -325,6 +328,7 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsig
     const float perRcp = 1.0f / (float) per;
     for (;;) {
         L.ended = false;
+        const unsigned long long t0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         // ---- refill: idle lanes take parked paths or the next items of the unit ----
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(L.st == L_IDLE);
         const bool haveNew = next < total;
@@ -356,9 +360,13 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsig
             if (next >= total && L.parked == 0u) break;
             continue;
         }
+        const unsigned long long t1 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         L.stage_slow();
+        const unsigned long long t2 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         L.stage_walk();
+        const unsigned long long t3 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         L.stage_shade();
+        if (COUNT) { const unsigned long long t4 = __builtin_amdgcn_s_memtime(); ss.tRefill += t1 - t0; ss.tSlow += t2 - t1; ss.tWalk += t3 - t2; ss.tShade += t4 - t3; }
         if (L.ended) {
             L.add_result(acc + (L.slotOff & 0xFFFFu));
             if (COST) lds_add(acc + 11u * (uint32_t) p.chunk + (L.slotOff >> 16), (uint32_t) L.bounces + 1u); // ~ Scene.hitObject calls of this path
@@ -411,6 +419,7 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
 
     for (;;) {
         L.ended = false;
+        const unsigned long long t0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         // ---- ranges: flush what has drained, reserve the next one when the current one has no items left ----
         if (prevNpx != 0u && prevOut == 0u) { flush(prevFirst, prevNpx, prevSlot); prevNpx = 0u; }
         if (curNext >= curTotal && prevNpx == 0u) {
@@ -489,9 +498,13 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
         }
         if (__builtin_amdgcn_ballot_w64(L.st != L_IDLE) == 0ull) continue;
 
+        const unsigned long long t1 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         L.stage_slow();
+        const unsigned long long t2 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         L.stage_walk();
+        const unsigned long long t3 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         L.stage_shade();
+        if (COUNT) { const unsigned long long t4 = __builtin_amdgcn_s_memtime(); ss.tRefill += t1 - t0; ss.tSlow += t2 - t1; ss.tWalk += t3 - t2; ss.tShade += t4 - t3; }
         if (L.ended) L.add_result(wv + L.slotOff);
         const bool inCur = (curNpx != 0u) && ((L.slotOff >= SW) == (curSlot == 1u));
         curOut -= (uint32_t) __popcll(__builtin_amdgcn_ballot_w64(L.ended && inCur));
@@ -548,6 +561,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     const unsigned long long tStart = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
     Counters cnt; cnt.rays = cnt.aabb = cnt.prim = cnt.refl = 0;
     StageStats ss; ss.refill = ss.trips = ss.leaf = ss.shade = ss.refillLanes = ss.shadeLanes = ss.slow = ss.slowLanes = ss.parkedLanes = 0;
+    ss.tRefill = ss.tSlow = ss.tWalk = ss.tShade = 0ull;
     uint32_t earlyCount = 0;
     uint64_t sampleCount = 0; // Scene.traceOnce calls = sum of PixelStats.Count
 
@@ -656,6 +670,10 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
             atomicAdd(&p.counters[20], (unsigned long long) ss.slow);
             atomicAdd(&p.counters[21], (unsigned long long) ss.slowLanes);
             atomicAdd(&p.counters[22], (unsigned long long) ss.parkedLanes);
+            atomicAdd(&p.counters[23], ss.tRefill);
+            atomicAdd(&p.counters[24], ss.tSlow);
+            atomicAdd(&p.counters[25], ss.tWalk);
+            atomicAdd(&p.counters[26], ss.tShade);
             const unsigned long long tEnd = __builtin_amdgcn_s_memrealtime();
             atomicAdd(&p.counters[14], tEnd - tStart);                         // sum of wave lifetimes
             atomicMax(&p.counters[15], tEnd);                                  // last wave to finish

@@ -241,6 +241,8 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
         case RT_TEXTURE_CHECKERED:
             if (t.even < 0 || t.odd < 0 || (size_t) t.even >= i || (size_t) t.odd >= i)
                 return "texture " + std::to_string(i) + ": Checkered children must have smaller indices";
+            // sin(gridSize * u), u in [0, 1]: csrc/rt_trig.h reduces arguments below 2^20 exactly
+            if (!(std::fabs(t.grid_size) <= 500000.0)) { status = RT_ERR_UNSUPPORTED; return "texture " + std::to_string(i) + ": Checkered grid size beyond 5e5 (or NaN)"; }
             break;
         case RT_TEXTURE_IMAGE: {
             if (!t.texels || t.width <= 0 || t.height <= 0) return "texture " + std::to_string(i) + ": image without texels";

@@ -83,7 +83,7 @@ static std::atomic<int> g_block_threads{0}, g_chunk_pixels{0}, g_blocks_per_cu{0
 static std::atomic<int> g_passes{0}; // 0 auto, 1 fused kernel, 2 two-pass (A, sort, B)
 static std::atomic<int> g_park_lanes{0};
 static std::atomic<int> g_walk_tree{RT_WALK_TREE_SAH};
-static thread_local unsigned long long g_last_stage_stats[12] = {0};
+static thread_local unsigned long long g_last_stage_stats[16] = {0};
 
 static int device_scene(rt_scene *s, int device, DeviceScene **out) {
     std::lock_guard<std::mutex> lock(s->mu);
@@ -246,9 +246,9 @@ int rt_set_launch_config(int32_t block_threads, int32_t chunk_pixels, int32_t bl
     return RT_OK;
 }
 
-int rt_last_stage_stats(uint64_t out[12]) {
+int rt_last_stage_stats(uint64_t out[16]) {
     if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
-    for (int i = 0; i < 12; ++i) out[i] = g_last_stage_stats[i];
+    for (int i = 0; i < 16; ++i) out[i] = g_last_stage_stats[i];
     return RT_OK;
 }
 
@@ -553,13 +553,13 @@ static int collect_stats(Pending &pd, rt_stats *stats) {
     unsigned long long c[32] = {0};
     if (pd.scr) {
         HIP_TRY(hipMemcpy(c, pd.scr, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(c + 16, pd.scr + 160, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(c + 16, pd.scr + 160, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
     for (int i = 0; i < 6; ++i) g_last_stage_stats[i] = c[8 + i];
     g_last_stage_stats[6] = c[14];                                  // sum of wave lifetimes, 100 MHz ticks
     g_last_stage_stats[7] = c[15] - (0x4000000000000000ull - c[7]); // first wave start -> last wave end, ticks
     g_last_stage_stats[8] = pd.waves;
-    g_last_stage_stats[9] = c[16]; g_last_stage_stats[10] = c[17]; g_last_stage_stats[11] = c[18];
+    for (int i = 0; i < 7; ++i) g_last_stage_stats[9 + i] = c[16 + i]; // slow stages, lanes in them, lanes parked, cycles in refill / slow / walk / shade
     float ms = 0.f;
     if (pd.launched) HIP_TRY(hipEventElapsedTime(&ms, pd.a, pd.b));
     memset(stats, 0, sizeof(*stats));
@@ -935,7 +935,10 @@ __global__ void k_arith(int op, int n, const double *a, const double *b, double 
     case 3: r = a[i] / b[i]; break;
     case 4: r = pow5(a[i]); break;
     case 5: r = sqrt_above_tol(a[i]); break;
-    default: r = inv_sqrt_above_tol(a[i]); break;
+    case 6: r = inv_sqrt_above_tol(a[i]); break;
+    case 7: r = rtt::cr_acos(a[i]); break;
+    case 8: r = rtt::cr_sin(a[i]); break;
+    default: r = rtt::cr_atan2(a[i], b[i]); break;
     }
     out[i] = r;
 }
@@ -1126,7 +1129,7 @@ int rt_dev_pixel_darken(int32_t device, int32_t n, const uint8_t *p, const doubl
 }
 
 int rt_dev_arith(int32_t device, int32_t op, int32_t n, const double *a, const double *b, double *out) {
-    if (!a || !out || n < 0 || op < 0 || op > 6 || (op == 3 && !b)) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!a || !out || n < 0 || op < 0 || op > 9 || ((op == 3 || op == 9) && !b)) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
     DeviceGuard guard;
     int rc = guard.enter(device);
     if (rc != RT_OK) return rc;

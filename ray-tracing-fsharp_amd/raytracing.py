@@ -405,10 +405,15 @@ class Scene:
             lib.rt_scene_destroy(h)
 
     @staticmethod
-    def make(objects: Sequence[Hittable]) -> "Scene":  # Scene.fs:15-28
+    def make(objects: Sequence[Hittable], walk_tree: Optional[str] = None) -> "Scene":  # Scene.fs:15-28
+        """walk_tree: None = the process default (set_walk_tree), "sah" or "reference" = this scene's own choice (rt_scene_create_ex)."""
         hs, n, tex, ntex, keep = flatten_hittables(objects)
         out = C.c_void_p()
-        check(lib.rt_scene_create(hs, n, tex, ntex, C.byref(out)))
+        if walk_tree is None:
+            check(lib.rt_scene_create(hs, n, tex, ntex, C.byref(out)))
+        else:
+            opt = A.rt_scene_options({"sah": A.RT_WALK_TREE_SAH, "reference": A.RT_WALK_TREE_REFERENCE}[walk_tree])
+            check(lib.rt_scene_create_ex(hs, n, tex, ntex, C.byref(opt), C.byref(out)))
         return Scene(out.value, keep)
 
     @property
@@ -449,19 +454,41 @@ class Scene:
         self.last_stats = st.as_dict()
         return RenderResult(accum, rgb, self.last_stats)
 
+    def render_frame(self, maxWidthCoord: int, maxHeightCoord: int, camera: Camera, *, seed: int = 0, devices: Sequence[int] = (0,),
+                     gather: int = A.RT_GATHER_AUTO, counters: bool = False, options: Optional[A.rt_render_options] = None) -> RenderResult:
+        """rt_render_frame: the whole frame on several GPUs from this one process (rows interleaved over `devices`, one gather);
+        stats is a list with one dict per device."""
+        rows, cols = 2 * maxHeightCoord + 1, 2 * maxWidthCoord + 1
+        accum = np.zeros((rows, cols, 4), np.int32)
+        rgb = np.zeros((rows, cols, 3), np.uint8)
+        devs = (C.c_int32 * len(devices))(*devices)
+        st = (A.rt_stats * len(devices))()
+        cam = camera.to_abi()
+        check(lib.rt_render_frame(self._h, C.byref(cam), maxWidthCoord, maxHeightCoord, seed, devs, len(devices),
+                                  A.RT_RENDER_COUNTERS if counters else 0, gather, C.byref(options) if options is not None else None,
+                                  _i32(accum), _u8(rgb), st))
+        return RenderResult(accum, rgb, [x.as_dict() for x in st])
+
     @staticmethod
     def render(progressIncrement: Callable[[float], None], log: Callable[[str], None], maxWidthCoord: int, maxHeightCoord: int,
-               camera: Camera, s: "Scene", *, seed: int = 0, device: int = 0) -> Tuple[float, Image]:
+               camera: Camera, s: "Scene", *, seed: int = 0, device: int = 0, row_block: Optional[int] = None) -> Tuple[float, Image]:
         """Scene.render (Scene.fs:196-236): returns (rows as progress units, lazy Image).  The work happens when the
-        Image is forced, exactly as in the reference; `progressIncrement 1.0` is then called once per row."""
+        Image is forced, exactly as in the reference, and `progressIncrement 1.0` is called once per row (Scene.fs:232) -- after
+        each block of `row_block` rows has come back (row_first/n_rows of the ABI), or after the whole frame when row_block is
+        None (one launch: fastest; at 0.2 s per frame the bar just jumps)."""
         rowsIter = 2 * maxHeightCoord + 1
         colsIter = 2 * maxWidthCoord + 1
 
         def force() -> np.ndarray:
-            res = s.render_rows(maxWidthCoord, maxHeightCoord, camera, seed=seed, device=device)
-            for _ in range(rowsIter):
-                progressIncrement(1.0)
-            return res.rgb
+            block = rowsIter if not row_block else max(1, int(row_block))
+            out = np.zeros((rowsIter, colsIter, 3), np.uint8)
+            for first in range(0, rowsIter, block):
+                n = min(block, rowsIter - first)
+                out[first:first + n] = s.render_rows(maxWidthCoord, maxHeightCoord, camera, seed=seed, device=device, row_first=first,
+                                                     row_stride=1, n_rows=n).rgb
+                for _ in range(n):
+                    progressIncrement(1.0)
+            return out
 
         return float(rowsIter), Image(rowsIter, colsIter, force)
 

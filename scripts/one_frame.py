@@ -36,7 +36,7 @@ for _ in range(a.launches):
     print({k: st[k] for k in ("kernel_ms", "rays", "aabb_tests", "prim_tests", "samples")}, flush=True)
     if a.counters:
         import ctypes
-        ss = (ctypes.c_uint64 * 12)()
+        ss = (ctypes.c_uint64 * 16)()
         rt.lib.rt_last_stage_stats(ss)
-        names = ("refill_stages", "node_trips", "leaf_stages", "shade_stages", "lanes_refilled", "lanes_shaded", "wave_ticks", "span_ticks", "waves", "slow_stages", "slow_lanes", "parked_lanes")
+        names = ("refill_stages", "node_trips", "leaf_stages", "shade_stages", "lanes_refilled", "lanes_shaded", "wave_ticks", "span_ticks", "waves", "slow_stages", "slow_lanes", "parked_lanes", "cyc_refill", "cyc_slow", "cyc_walk", "cyc_shade")
         print(dict(zip(names, list(ss))), flush=True)

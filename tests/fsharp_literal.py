@@ -225,15 +225,37 @@ def bbox_hits(inv, ray, box):
 # ---- Texture.fs -------------------------------------------------------------------------------------------------------
 # Texture = ("Colour", pixel) | ("Arbitrary", point -> pixel); ParameterisedTexture = ("Colour", pixel) |
 # ("Checkered", even, odd, gridSize) | ("Image", rows) | ("Arbitrary", x -> y -> Texture), closures as in F#.
+# Math.Acos / Math.Atan2 / Math.Sin are the C runtime's in .NET; the path defines them as the correctly rounded values
+# (csrc/rt_trig.h).  Third route, after the device's double-double and the oracle's binary128: mpmath at 250 bits, rounded once.
+# Zeros, infinities and NaNs (exact in every libm) go to math.*.
+import mpmath as _mp
+
+_mp.mp.prec = 250
+
+
+def _plain(*xs):
+    return all(x == x and abs(x) != math.inf and x != 0.0 for x in xs)
+
+
 def facos(x):  # F# `acos` outside [-1, 1] is NaN; math.acos raises instead
-    return math.acos(x) if -1.0 <= x <= 1.0 else NAN
+    if not -1.0 <= x <= 1.0:
+        return NAN
+    return float(_mp.acos(_mp.mpf(x))) if _plain(x) else math.acos(x)
+
+
+def fatan2(y, x):
+    return float(_mp.atan2(_mp.mpf(y), _mp.mpf(x))) if _plain(y, x) else math.atan2(y, x)
+
+
+def fsin(x):
+    return float(_mp.sin(_mp.mpf(x))) if _plain(x) else math.sin(x)
 
 
 def plane_map_inverse(radius, centre):  # Sphere.fs:55-61, curried like the reference's use of it
     def interpret(p):
         x, y, z = v_scale(1.0 / radius, v_diff(p, centre))
         theta = facos(-y)
-        phi = math.atan2(-z, x) + math.pi
+        phi = fatan2(-z, x) + math.pi
         return (phi / (2.0 * math.pi)), theta / math.pi
     return interpret
 
@@ -251,7 +273,7 @@ def param_colour_at(interpret, t, p):  # Texture.fs:50-67
     if t[0] == "Checkered":
         _, even, odd, gridSize = t
         x, y = interpret(p)
-        sine = math.sin(gridSize * x) * math.sin(gridSize * y)
+        sine = fsin(gridSize * x) * fsin(gridSize * y)
         if f_compare(sine, 0.0) == "Less":
             return param_colour_at(interpret, even, p)
         return param_colour_at(interpret, odd, p)
