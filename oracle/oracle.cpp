@@ -395,6 +395,20 @@ static inline Point planeMap(double radius, Point centre, double phi, double the
                                     -radius * std::sin(phi) * std::sin(theta)));
 }
 
+// `int (v * float (n - 1))` (Texture.fs:65-66) as an index into n texels: the reference's truncation for a coordinate in [0, 1].
+// Outside it (Math.Acos is NaN for a point a rounding error off its sphere) the reference throws IndexOutOfRangeException; the
+// defined behaviour, here and on the device: NaN and negative products take texel 0, products beyond the end the last texel.
+static inline int texelIndex(double v, int n) {
+    const double t = v * (double) (n - 1);
+    if (!(t >= 0.0)) return 0;
+    if (t >= (double) (n - 1)) return n - 1;
+    return (int) t;
+}
+static inline uint8_t rampByte(double v) { // byte (v * 255.0); NaN -> 0 on both sides
+    const double t = v * 255.0;
+    return (t == t) ? (uint8_t) (int32_t) t : (uint8_t) 0;
+}
+
 // ParameterisedTexture.colourAt (Texture.fs:50-67); (x, y) = interpret p is evaluated by the caller once:
 // every branch that needs it calls the same pure `interpret p`.
 static Pixel paramColourAt(const TextureTable &tt, int id, double x, double y) {
@@ -405,8 +419,8 @@ static Pixel paramColourAt(const TextureTable &tt, int id, double x, double y) {
     case RT_TEXTURE_UV_RAMP: { // Texture.fs:53-55 with the closures of RayTracing.App/SampleImages.fs:606-627
         uint8_t c[3];
         for (int k = 0; k < 3; ++k) {
-            if (t.ramp_src[k] == RT_RAMP_U) c[k] = (uint8_t) (int32_t) (x * 255.0);      // byte (float x * 255.0)
-            else if (t.ramp_src[k] == RT_RAMP_V) c[k] = (uint8_t) (int32_t) (y * 255.0); // byte (y * 255.0)
+            if (t.ramp_src[k] == RT_RAMP_U) c[k] = rampByte(x);      // byte (float x * 255.0)
+            else if (t.ramp_src[k] == RT_RAMP_V) c[k] = rampByte(y); // byte (y * 255.0)
             else c[k] = t.rgb[k];
         }
         return Pixel{c[0], c[1], c[2]};
@@ -417,8 +431,8 @@ static Pixel paramColourAt(const TextureTable &tt, int id, double x, double y) {
         return paramColourAt(tt, t.odd, x, y);
     }
     case RT_TEXTURE_IMAGE: { // Texture.fs:63-67
-        int xi = (int) ((1.0 - x) * (double) (t.width - 1));
-        int yi = (int) (y * (double) (t.height - 1));
+        int xi = texelIndex(1.0 - x, t.width);
+        int yi = texelIndex(y, t.height);
         const uint8_t *px = &tt.texels[(size_t) id][((size_t) yi * (size_t) t.width + (size_t) xi) * 3];
         return Pixel{px[0], px[1], px[2]};
     }

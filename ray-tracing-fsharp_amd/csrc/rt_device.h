@@ -492,6 +492,20 @@ RTD_INLINE int hit_object(const SceneView<LDS> &sc, V3 o, V3 d, double &bestLen,
 }
 
 // ---- Textures (Texture.fs:50-67, Sphere.planeMapInverse Sphere.fs:55-61) --------------------------------------------
+// `int (v * float (n - 1))` of Texture.fs:65-66 as an index into n texels.  For a coordinate in [0, 1] this is the reference's
+// truncation.  Outside it -- a point a rounding error off the sphere makes Math.Acos return NaN, and `int NaN` then indexes out of
+// range -- the reference throws IndexOutOfRangeException; the defined behaviour here (and in the oracle): NaN and negative
+// products take texel 0, products beyond the last texel take the last one.
+RTD_INLINE int texel_index(double v, int n) {
+    const double t = v * (double) (n - 1);
+    if (!(t >= 0.0)) return 0;
+    if (t >= (double) (n - 1)) return n - 1;
+    return (int) t;
+}
+RTD_INLINE uint32_t ramp_byte(double v) { // byte (v * 255.0) (RayTracing.App/SampleImages.fs:606-627); NaN -> 0 on both sides
+    const double t = v * 255.0;
+    return (t == t) ? (((uint32_t) (int32_t) t) & 0xFFu) : 0u;
+}
 // Rare (only textured spheres), transcendental-heavy (double-double arithmetic, rt_trig.h): kept out of line so the common path stays small.
 __device__ __noinline__ uint32_t texture_colour_at(const TexRec *tex, const uint8_t *texels, int id, V3 p, double *uv) {
     const TexRec root = tex[id];
@@ -513,8 +527,8 @@ __device__ __noinline__ uint32_t texture_colour_at(const TexRec *tex, const uint
             continue;
         }
         if (t.kind == 2u) { // Image (Texture.fs:63-67): truncating int conversions
-            int xi = (int) ((1.0 - x) * (double) (t.width - 1));
-            int yi = (int) (y * (double) (t.height - 1));
+            int xi = texel_index(1.0 - x, t.width);
+            int yi = texel_index(y, t.height);
             const uint8_t *px = texels + t.texel_off + ((size_t) yi * (size_t) t.width + (size_t) xi) * 3;
             return (uint32_t) px[0] | ((uint32_t) px[1] << 8) | ((uint32_t) px[2] << 16);
         }
@@ -523,8 +537,8 @@ __device__ __noinline__ uint32_t texture_colour_at(const TexRec *tex, const uint
             for (int k = 0; k < 3; ++k) {
                 uint32_t src = (t.ramp >> (8 * k)) & 0xFFu;
                 uint32_t ch = (t.rgb >> (8 * k)) & 0xFFu;
-                if (src == 1u) ch = ((uint32_t) (int32_t) (x * 255.0)) & 0xFFu;
-                else if (src == 2u) ch = ((uint32_t) (int32_t) (y * 255.0)) & 0xFFu;
+                if (src == 1u) ch = ramp_byte(x);
+                else if (src == 2u) ch = ramp_byte(y);
                 c |= ch << (8 * k);
             }
             return c;

@@ -211,13 +211,12 @@ def test_device_trig_is_the_correctly_rounded_value(rt, orc):
     a = np.concatenate([rng.uniform(-100, 100, n), rng.uniform(-1e5, 1e5, 50000), np.arange(1, 20000) * (np.pi / 2),
                         rng.choice([-1.0, 1.0], 5000) * 10.0 ** rng.uniform(-300, 0, 5000), [0.0, -0.0, np.nan, np.inf, -np.inf, 5e-324, 1048575.5]])
     got, want = rt.hooks.arith(8, a), orc.arith(8, a)
-    assert _same_f64(got, want) and np.array_equal(np.signbit(got), np.signbit(want))
+    assert _same_f64(got, want)  # bit patterns, so the signs of zeros too (the sign of a NaN is not compared)
     y = np.concatenate([rng.normal(size=n), rng.normal(size=30000) * 10.0 ** rng.uniform(-200, 200, 30000),
                         [0.0, -0.0, 0.0, -0.0, 0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.inf, -np.inf, 1.0, -1.0, np.nan, 1.0]])
     xx = np.concatenate([rng.normal(size=n), rng.normal(size=30000) * 10.0 ** rng.uniform(-200, 200, 30000),
                          [1.0, 1.0, -1.0, -1.0, 0.0, -0.0, 0.0, -0.0, np.inf, np.inf, -np.inf, -np.inf, np.inf, -np.inf, 1.0, np.nan]])
-    got, want = rt.hooks.arith(9, y, xx), orc.arith(9, y, xx)
-    assert _same_f64(got, want) and np.array_equal(np.signbit(got), np.signbit(want))
+    assert _same_f64(rt.hooks.arith(9, y, xx), orc.arith(9, y, xx))
 
 
 def test_texture_lookup(rt, orc):
