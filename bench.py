@@ -19,13 +19,41 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TF = 78.6  # MI355X vector FP64 spec: 256 CUs x 4 SIMDs x 16 lanes x 2 (FMA) x 2.4 GHz
 
 
 def algorithmic_bytes(st) -> int:
     """56 B per ray-AABB test (6 doubles + 2 links), 32 B per ray-primitive test (centre + r^2),
     40 B material record per shaded vertex, 4 B packed RGB per finished sample."""
     return 56 * st["aabb_tests"] + 32 * st["prim_tests"] + 40 * st["reflections"] + 4 * st["samples"]
+
+
+def algorithmic_flops(st) -> int:
+    """18 flops per ray-AABB test (6 sub, 6 mul, 6 compare-select), 17 per ray-primitive test, 3 per ray
+    (inverseDirections).  The exactness contract forbids contraction, so none of them can be half of an FMA."""
+    return 18 * st["aabb_tests"] + 17 * st["prim_tests"] + 3 * st["rays"]
+
+
+def measured_issue_ceiling():
+    """TFLOP/s of non-FMA FP64 (one flop per lane per instruction) at the issue cost MEASURED on this chip: the newest
+    profiles/r*/valu_rates.txt (output of scripts/ubench/valu_rates.hip) -- cycles per wave64 v_add_f64 / v_mul_f64 / v_max_f64 per
+    SIMD at 4 waves per SIMD, at the clock that file reports.  (None, None) when no such file is committed."""
+    import glob
+    import re
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "valu_rates.txt")))
+    if not files:
+        return None, None
+    txt = open(files[-1]).read()
+    clk = re.search(r"clock (\d+) kHz", txt)
+    row = [ln for ln in txt.splitlines() if ln.startswith("waves/SIMD 4:")]
+    if not clk or not row:
+        return None, None
+    cyc = [float(re.search(name + r"=([0-9.]+)", row[0]).group(1)) for name in ("v_add_f64", "v_mul_f64", "v_max_f64")]
+    mean = sum(cyc) / len(cyc)
+    return 1024 * 64 * (float(clk.group(1)) * 1e3) / mean / 1e12, {"file": os.path.relpath(files[-1], ROOT), "cycles_per_wave64_f64_op": round(mean, 2),
+                                                                   "clock_khz": int(clk.group(1))}
 
 
 def profiled_traffic():
@@ -242,12 +270,22 @@ def main():
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
         value = job["rays"] / (ms_per_step * 1e-3) / 1e6
-        # dominant (only) kernel: rtd::render_kernel.  achieved = this rank's algorithmic bytes per launch / its mean launch time
+        # dominant (only) kernel: rtd::render_kernel.  What binds it is VALU issue of FP64 work (no MFMA: nothing here is a
+        # contraction; no HBM: the scene lives in LDS), so the roofline is the FP64 vector one: this rank's algorithmic flops per
+        # launch / its mean launch time, against the 78.6 TF spec, and beside it against what this chip was MEASURED to issue when
+        # every instruction is a plain add/mul/max (no FMA: contraction is off by contract).
         rank_bytes = algorithmic_bytes(st)
-        achieved = rank_bytes / (kernel_ms * 1e-3) / 1e9
+        rank_flops = algorithmic_flops(st)
+        achieved_tf = rank_flops / (kernel_ms * 1e-3) / 1e12
+        ceiling_tf, ceiling_src = measured_issue_ceiling()
         info = scene.info()
-        traffic, src = profiled_traffic() if world == 1 else (None, None)
+        traffic, src = profiled_traffic() if (world == 1 and args.workload == "c3") else (None, None)  # the committed PMC passes are of config 3
         traffic_src, physical = src if src else (None, None)
+        limited = None
+        if physical:
+            limited = (f"VALU issue: a vector instruction in flight {100 * physical['valu_issue_busy_frac']:.0f} % of all SIMD cycles at "
+                       f"{100 * physical['valu_lane_utilisation']:.0f} % lane occupancy, {physical['valu_wave_instructions']:.3g} wave instructions per frame "
+                       f"(PMC, {traffic_src}); neither HBM nor MFMA")
         out = {
             "metric": "Mray/s (primary+secondary)", "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
@@ -266,11 +304,19 @@ def main():
                     "primary_rays_per_s": round(job["samples"] / (ms_per_step * 1e-3), 1),
                     "mean_hits_per_path": round(job["reflections"] / max(1, job["samples"]), 4),
                     "early_exit_fraction": round(job["pixels_early"] / (rows * cols), 4)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src, "physical_from_same_profile": physical,
-                         "kernel": "rtd::render_kernel", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": rank_bytes,
-                         "limited_by": "VALU issue (busy fraction below) at ~57 % lane occupancy; neither HBM nor MFMA (DESIGN.md section 4)",
-                         "note": "achieved = algorithmic scene bytes / kernel time; LDS serves them, hence frac > 1; `traffic` is the physical HBM byte count"},
+            "roofline": {"bound": "fp64_vector", "achieved": round(achieved_tf, 3), "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(achieved_tf / FP64_VECTOR_PEAK_TF, 5),
+                         "peak_measured_non_fma_issue": round(ceiling_tf, 2) if ceiling_tf else None,
+                         "frac_of_measured_non_fma_issue": round(achieved_tf / ceiling_tf, 4) if ceiling_tf else None,
+                         "measured_issue_source": ceiling_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "physical_from_same_profile": physical,
+                         "kernel": "rtd::render_kernel", "kernel_ms": round(kernel_ms, 3), "algorithmic_flops_per_launch": rank_flops,
+                         "limited_by": limited,
+                         "algorithmic_hbm_equiv": {"bytes_per_launch": rank_bytes, "gb_per_s": round(rank_bytes / (kernel_ms * 1e-3) / 1e9, 1),
+                                                   "of_hbm_peak": round(rank_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 3),
+                                                   "note": "SURVEY.md 8(d)'s scene bytes the algorithm touches (56 B per box test, ...), served by LDS -- "
+                                                           "not HBM traffic and not a roofline fraction; `traffic` is the physical HBM byte count per launch"},
+                         "note": "achieved = algorithmic FP64 flops (18 per box test, 17 per sphere test, 3 per ray) / mean kernel time"},
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(objs, cam, w, h, args.seed, args.cpu_seconds)
