@@ -65,7 +65,7 @@ def profiled_traffic():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_bench_config_summary.csv")))
     if not files:
         return None, None
-    vals = dict(line.strip().split(",") for line in open(files[-1]) if "," in line)
+    vals = dict(line.strip().split(",") for line in open(files[-1]) if "," in line and not line.startswith("#"))
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None, None
     phys = None

@@ -4,6 +4,7 @@
 #include "rtfs_amd.h"
 
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -13,10 +14,44 @@
         if (!(cond)) { fprintf(stderr, "FAILED %s (line %d): %s\n", #cond, __LINE__, rt_last_error()); return 1; } \
     } while (0)
 
+/* The layout a [<StructLayout(LayoutKind.Sequential)>] F# struct gets: fields in order, each at the next multiple
+ * of its element's natural alignment (.NET's default Pack = 8 never bites: no field here is wider than 8), size rounded up to the
+ * widest alignment.  fields = {element size, element count} per field, in declaration order.  Every offset must equal the one the
+ * library was compiled with (rt_abi_offsetof) -- the check the F# shim makes with Marshal.OffsetOf at start-up. */
+static int sequential_layout_matches(int which, const int (*fields)[2], int n_fields) {
+    size_t off = 0, widest = 1;
+    for (int i = 0; i < n_fields; ++i) {
+        const size_t al = (size_t) fields[i][0];
+        off = (off + al - 1) / al * al;
+        if (rt_abi_offsetof(which, i) != off) { fprintf(stderr, "struct %d field %d: sequential layout %zu, library %zu\n", which, i, off, rt_abi_offsetof(which, i)); return 0; }
+        off += al * (size_t) fields[i][1];
+        if (al > widest) widest = al;
+    }
+    off = (off + widest - 1) / widest * widest;
+    return rt_abi_offsetof(which, n_fields) == (size_t) -1 && rt_abi_sizeof(which) == off;
+}
+
 int main(void) {
     CHECK(rt_abi_version() == RT_ABI_VERSION);
     CHECK(rt_abi_sizeof(0) == sizeof(rt_hittable) && rt_abi_sizeof(1) == sizeof(rt_texture) && rt_abi_sizeof(2) == sizeof(rt_camera));
     CHECK(rt_abi_sizeof(3) == sizeof(rt_scene_info) && rt_abi_sizeof(4) == sizeof(rt_stats));
+    CHECK(rt_abi_sizeof(5) == sizeof(rt_render_options) && rt_abi_sizeof(6) == sizeof(rt_scene_options));
+    {   /* the field lists of INTEGRATION.md's F# mirrors: RtHittable (104 bytes, texture at 100), RtTexture, RtCamera, ... */
+        static const int hittable[][2] = {{4, 1}, {4, 1}, {8, 3}, {8, 3}, {8, 1}, {8, 1}, {8, 1}, {8, 1}, {8, 1}, {1, 3}, {1, 1}, {4, 1}};
+        static const int texture[][2] = {{4, 1}, {1, 3}, {1, 3}, {1, 2}, {4, 1}, {4, 1}, {8, 1}, {4, 1}, {4, 1}, {8, 1}, {8, 3}, {8, 1}};
+        static const int camera[][2] = {{8, 3}, {8, 3}, {8, 3}, {8, 3}, {8, 3}, {8, 3}, {8, 1}, {8, 1}, {8, 1}, {4, 1}, {4, 1}};
+        static const int info[][2] = {{4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {8, 1}, {8, 1}};
+        static const int stats[][2] = {{8, 1}, {8, 1}, {8, 1}, {8, 1}, {8, 1}, {8, 1}, {8, 1}, {8, 1}, {8, 1}};
+        static const int ropt[][2] = {{4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}};
+        static const int sopt[][2] = {{4, 1}, {4, 1}};
+        CHECK(sequential_layout_matches(0, hittable, 12) && sizeof(rt_hittable) == 104 && rt_abi_offsetof(0, 11) == 100);
+        CHECK(sequential_layout_matches(1, texture, 12));
+        CHECK(sequential_layout_matches(2, camera, 11));
+        CHECK(sequential_layout_matches(3, info, 10) && sequential_layout_matches(4, stats, 9));
+        CHECK(sequential_layout_matches(5, ropt, 8) && sequential_layout_matches(6, sopt, 2));
+        CHECK(rt_abi_offsetof(0, 3) == offsetof(rt_hittable, normal) && rt_abi_offsetof(1, 9) == offsetof(rt_texture, texels));
+        CHECK(rt_abi_offsetof(7, 0) == (size_t) -1);
+    }
 
     /* Camera.makeBasic for the final scene */
     const double origin[3] = {13.0, 2.0, -3.0}, up[3] = {0.0, 1.0, 0.0};
@@ -66,6 +101,18 @@ int main(void) {
         CHECK(rc == RT_OK);
         CHECK(st.pixels == 49 && st.samples >= 49 * 11 && st.rays >= st.samples);
         CHECK(accum[0] == 11 || accum[0] == 20);
+        /* Scene.render on "several" devices from this one process (the list repeats the one GPU of the box), with per-call
+         * launch options: the very same PixelStats */
+        const int32_t devices[3] = {0, 0, 0};
+        rt_render_options opt;
+        memset(&opt, 0, sizeof(opt));
+        opt.struct_size = (uint32_t) sizeof(opt); opt.block_threads = 256; opt.passes = 2; opt.park_lanes = 8;
+        int32_t accum2[7 * 7 * 4];
+        uint8_t rgb2[7 * 7 * 3];
+        rt_stats st3[3];
+        CHECK(rt_render_frame(scene, &cam, 3, 3, 42, devices, 3, RT_RENDER_COUNTERS, RT_GATHER_PEER, &opt, accum2, rgb2, st3) == RT_OK);
+        CHECK(memcmp(accum, accum2, sizeof(accum)) == 0 && memcmp(rgb, rgb2, sizeof(rgb)) == 0);
+        CHECK(st3[0].rays + st3[1].rays + st3[2].rays == st.rays && st3[0].pixels == 21 && st3[2].pixels == 14);
         printf("abi_smoke: host checks ok, rendered 7x7 px: %llu samples, %llu rays\n", (unsigned long long) st.samples, (unsigned long long) st.rays);
     }
     rt_scene_destroy(scene);
