@@ -61,9 +61,10 @@ struct RenderParams {
 // Per-wave LDS scratch (in 4-byte words), P = pixels per work unit:
 //   acc  [2][P][3]  sums of slot 0 / slot 1
 //   pix  [P][4]     row, col, pixel stream key lo, hi
-//   live [P]        compacted pixel slots for phase 2
-//   cost [P]        rays traced for the pixel in phase 1 (pass A only: the cost estimate that orders pass B)
-#define RTD_WAVE_WORDS(P) (14u * (uint32_t) (P)) /* pass B uses it as two slots of {acc [P][3], pix [P][4]} */
+//   live [P]        compacted pixel slots for phase 2 (fused mode), or
+//   cost [P]        rays traced for the pixel in phase 1 (pass A: the cost estimate that orders pass B; pass A has no phase 2)
+#define RTD_WAVE_WORDS(P) (14u * (uint32_t) (P)) /* fused: 11 P used; pass B uses it as two slots of {acc [P][3], pix [P][4]} */
+#define RTD_WAVE_WORDS_A(P) (11u * (uint32_t) (P)) /* pass A: acc, pix, cost -- a tighter footprint, so its units can be wider */
 
 // Wave-private LDS words: adds from many lanes may land on one word (same pixel), so they are ds_add_u32; the owner
 // lane later takes the sum and clears the word in one ds_wrxchg.  One wave's LDS operations execute in order.
@@ -369,7 +370,7 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsig
         if (COUNT) { const unsigned long long t4 = __builtin_amdgcn_s_memtime(); ss.tRefill += t1 - t0; ss.tSlow += t2 - t1; ss.tWalk += t3 - t2; ss.tShade += t4 - t3; }
         if (L.ended) {
             L.add_result(acc + (L.slotOff & 0xFFFFu));
-            if (COST) lds_add(acc + 11u * (uint32_t) p.chunk + (L.slotOff >> 16), (uint32_t) L.bounces + 1u); // ~ Scene.hitObject calls of this path
+            if (COST) lds_add(acc + 10u * (uint32_t) p.chunk + (L.slotOff >> 16), (uint32_t) L.bounces + 1u); // ~ Scene.hitObject calls of this path
         }
     }
 }
@@ -546,7 +547,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
         __syncthreads();
     }
     const uint32_t P = (uint32_t) p.chunk;
-    RTD_AS3 uint32_t *wv = (RTD_AS3 uint32_t *) (smem + sceneBytes) + (size_t) wave * RTD_WAVE_WORDS(P);
+    RTD_AS3 uint32_t *wv = (RTD_AS3 uint32_t *) (smem + sceneBytes) + (size_t) wave * (MODE == 1 ? RTD_WAVE_WORDS_A(P) : RTD_WAVE_WORDS(P));
     RTD_AS3 uint32_t *acc = wv;
     RTD_AS3 uint32_t *pix = wv + 6u * P;
     RTD_AS3 uint32_t *live = pix + 4u * P;
@@ -577,7 +578,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
 
         // per-pixel coordinates (Scene.fs:219,226) and stream key; clear the accumulators
         for (uint32_t i = (uint32_t) lane; i < 6u * P; i += 64u) acc[i] = 0u;
-        if (MODE == 1 && (uint32_t) lane < P) acc[11u * P + lane] = 0u;
+        if (MODE == 1 && (uint32_t) lane < P) acc[10u * P + lane] = 0u;
         unsigned long long lp = 0; // local pixel of lane j < npx
         if ((uint32_t) lane < npx) {
             lp = first + (uint32_t) lane;
@@ -622,7 +623,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(p.live_count, nLive);
             base = __builtin_amdgcn_readfirstlane(base);
-            if (cont) p.pairs[base + pos] = ((unsigned long long) acc[11u * P + lane] << 32) | (unsigned long long) (uint32_t) lp;
+            if (cont) p.pairs[base + pos] = ((unsigned long long) acc[10u * P + lane] << 32) | (unsigned long long) (uint32_t) lp;
         }
         __builtin_amdgcn_wave_barrier();
 

@@ -138,8 +138,8 @@ static const char *check_settings(const Settings &s) {
     if (s.park < -1 || s.park > RTD_MAX_PARK) return "park_lanes must be in [-1, 256]";
     return nullptr;
 }
-static size_t lds_need(const rth::HostScene &h, bool lds, int block, int chunk) {
-    return (lds ? (size_t) h.off.lds_total : 0u) + (size_t) (block / 64) * RTD_WAVE_WORDS(chunk) * 4u;
+static size_t lds_need(const rth::HostScene &h, bool lds, int block, int chunk, bool passA = false) {
+    return (lds ? (size_t) h.off.lds_total : 0u) + (size_t) (block / 64) * (passA ? RTD_WAVE_WORDS_A(chunk) : RTD_WAVE_WORDS(chunk)) * 4u;
 }
 struct LaunchPlan {
     int block = 1024, chunk = 16, park = 0;
@@ -517,9 +517,9 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
             }
             // both passes must fit the LDS beside the scene image, decided BEFORE anything is launched (a misfit found after
             // pass A would leave a half-rendered buffer); 
-            while (lds && chunkA > 1 && lds_need(h, true, block, chunkA) > RT_LDS_BYTES) chunkA /= 2;
+            while (lds && chunkA > 1 && lds_need(h, true, block, chunkA, true) > RT_LDS_BYTES) chunkA /= 2;
             while (lds && chunkB > 1 && lds_need(h, true, block, chunkB) > RT_LDS_BYTES) chunkB /= 2;
-            const size_t ldsA = lds_need(h, lds, block, chunkA), ldsB = lds_need(h, lds, block, chunkB);
+            const size_t ldsA = lds_need(h, lds, block, chunkA, true), ldsB = lds_need(h, lds, block, chunkB);
             if (lds && (ldsA > RT_LDS_BYTES || ldsB > RT_LDS_BYTES)) return fail(RT_ERR_HIP, "two-pass launch does not fit the LDS");
             HIP_TRY(hipFuncSetAttribute((const void *) fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsA));
             HIP_TRY(hipFuncSetAttribute((const void *) fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsB));
