@@ -555,7 +555,10 @@ __device__ __noinline__ uint32_t texture_colour_at(const TexRec *tex, const uint
 // stage once, so Pure/Fuzzed/Dielectric/Glass spheres and Pure/Fuzzed planes all share one mirror computation.
 enum { ACT_REFLECT = 1, ACT_REFRACT = 2, ACT_FUZZ = 4, ACT_LAMBERT = 8, ACT_LAMBERT_ONCE = 16 };
 
-template <bool LDS>
+// TEX = false compiles the function without the (out-of-line) texture evaluation, for scenes that have no parameterised
+// texture: the call is what costs the render kernel its spills (with it: 128 VGPRs, ~50 VGPR and ~115 SGPR spills, 204 B of
+// scratch; without: 0 scratch, 0 VGPR spills, 9 SGPR spills for the pass-B instantiation).
+template <bool LDS, bool TEX = true>
 RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, V3 &d, uint32_t &colour, Rng &rng) {
     const i2 m = sc.meta[obj];
     const bool isPlane = (m.x & 3) == (int) RTD_KIND_PLANE;
@@ -567,7 +570,7 @@ RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, 
     const int texId = (int) (((uint32_t) m.y) >> 24) - 1;
     // Styles that carry a Texture: every SphereStyle but LightSourceCap (Sphere.fs:10-37), and the plane LightSource
     // (InfinitePlane.fs:5); the other plane styles carry a plain Pixel.  The host rejects a texture id elsewhere.
-    if (texId >= 0 && (isPlane ? style == 0 : style != 1))
+    if (TEX && texId >= 0 && (isPlane ? style == 0 : style != 1))
         texColour = texture_colour_at(sc.tex, sc.texels, texId, strike, nullptr);
 
     V3 n;              // normal.Vector (possibly flipped)

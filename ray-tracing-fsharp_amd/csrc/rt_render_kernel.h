@@ -133,7 +133,7 @@ struct StageStats { // wave-uniform, COUNT variant only
 #define RTD_PARK_ENTRY_BYTES 96 /* 5 x 16 B + 8 B, padded */
 enum { L_IDLE = 0, L_WALK = 1, L_DONE = 2, L_SLOW = 3 };
 
-template <bool LDS, bool COUNT>
+template <bool LDS, bool COUNT, bool TEX>
 struct Sched {
     const RenderParams &p;
     const SceneView<LDS> &sc;
@@ -239,7 +239,7 @@ struct Sched {
         if (COUNT) { ss.slow++; ss.slowLanes += (uint32_t) __popcll(m); }
         if (st == L_SLOW) {
             const V3 strike = walk(o, d, w.bestLen); // Ray.walkAlong ray bestLength (Scene.fs:91)
-            after_reflection(reflection<LDS>(sc, w.best, strike, o, d, colour, rng));
+            after_reflection(reflection<LDS, TEX>(sc, w.best, strike, o, d, colour, rng));
         }
     }
 
@@ -319,11 +319,11 @@ struct Sched {
 
 // Trace `total` items of the current unit.  Item i belongs to pixel slot map[i / per] (or i / per when map is null)
 // and is sample s_base + i % per of that pixel; its colour is added to accumulator slot (sample < split ? 0 : 1).
-template <bool LDS, bool COUNT, bool COST>
+template <bool LDS, bool COUNT, bool COST, bool TEX>
 RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsigned char *pool, RTD_AS3 uint32_t *acc, const RTD_AS3 uint32_t *pix,
                           const RTD_AS3 uint32_t *live, bool use_live, uint32_t total, uint32_t per, uint32_t s_base,
                           uint32_t split, Counters &cnt, StageStats &ss) {
-    Sched<LDS, COUNT> L(p, sc, cnt, ss, pool);
+    Sched<LDS, COUNT, TEX> L(p, sc, cnt, ss, pool);
     uint32_t next = 0; // wave-uniform
     const bool fastDiv = total < (1u << 22) && per < (1u << 23); // see div_uniform
     const float perRcp = 1.0f / (float) per;
@@ -380,14 +380,14 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsig
 // hands out its items: two accumulator slots alternate, a range is flushed (its sums added to what pass A left in `accum`) when
 // its last path has ended.  There is no dependency between ranges, so no lane waits at a range boundary -- which is what makes
 // small ranges (good load balance across waves) affordable.  Lane states and stage scheduling are Sched's.
-template <bool LDS, bool COUNT>
+template <bool LDS, bool COUNT, bool TEX>
 RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsigned char *pool, RTD_AS3 uint32_t *wv, uint32_t n1, uint32_t n2, Counters &cnt,
                            StageStats &ss, uint64_t &sampleCount) {
     const int lane = threadIdx.x & 63;
     const uint32_t P = (uint32_t) p.chunk;
     const uint32_t SW = 7u * P; // words per slot: acc [P][3] then pix [P][4]
     const unsigned long long nList = (unsigned long long) *p.live_count;
-    Sched<LDS, COUNT> L(p, sc, cnt, ss, pool); // slotOff: word offset from wv of the path's accumulator triple (>= SW: slot 1)
+    Sched<LDS, COUNT, TEX> L(p, sc, cnt, ss, pool); // slotOff: word offset from wv of the path's accumulator triple (>= SW: slot 1)
 
     // wave-uniform: the range being handed out (cur) and the one draining (prev)
     unsigned long long curFirst = 0, prevFirst = 0;
@@ -521,7 +521,8 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
 // Per-pixel cost is heavy-tailed (a pixel on a glass sphere: ~20 rays per sample, 4 ms of one wave), so when a shard has only a few
 // units per wave the fused kernel ends with most waves waiting for a few long units started late; A + sort + B removes that tail.
 // Every mode computes the same integers: which wave traces which sample when has no effect (streams are per item).
-template <bool LDS, bool COUNT, int BLOCK, int MODE>
+// TEX: the scene has parameterised textures (see `reflection`).
+template <bool LDS, bool COUNT, int BLOCK, int MODE, bool TEX>
 __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -566,7 +567,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     uint32_t earlyCount = 0;
     uint64_t sampleCount = 0; // Scene.traceOnce calls = sum of PixelStats.Count
 
-    if (MODE == 2) run_stream<LDS, COUNT>(p, sc, pool, wv, n1, n2, cnt, ss, sampleCount);
+    if (MODE == 2) run_stream<LDS, COUNT, TEX>(p, sc, pool, wv, n1, n2, cnt, ss, sampleCount);
     else
     for (;;) {
         uint32_t unit = 0;
@@ -594,7 +595,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
         __builtin_amdgcn_wave_barrier();
 
         // ---- phase 1: 2k+1 samples per pixel, sums split after sample k (Scene.fs:172-182) ----
-        run_items<LDS, COUNT, MODE == 1>(p, sc, pool, acc, pix, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
+        run_items<LDS, COUNT, MODE == 1, TEX>(p, sc, pool, acc, pix, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
         __builtin_amdgcn_wave_barrier();
 
         // ---- decide (Scene.fs:177-188) and compact the pixels that continue ----
@@ -629,7 +630,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
 
         // ---- phase 2: the remaining spp-2k-1 samples of the surviving pixels (Scene.fs:191-192) ----
         if (MODE == 0 && nLive > 0u) {
-            run_items<LDS, COUNT, false>(p, sc, pool, acc, pix, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
+            run_items<LDS, COUNT, false, TEX>(p, sc, pool, acc, pix, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
             __builtin_amdgcn_wave_barrier();
         }
 

@@ -162,24 +162,26 @@ static LaunchPlan plan_launch(const rth::HostScene &h, const Settings &s) {
 // launch
 // ------------------------------------------------------------------------------------------------------------
 typedef void (*render_fn)(const RenderParams);
-template <int MODE> static render_fn pick_mode(bool lds, bool count, int block) {
+template <int MODE, bool TEX> static render_fn pick_mode(bool lds, bool count, int block) {
     if (block == 1024) {
-        if (lds) return count ? render_kernel<true, true, 1024, MODE> : render_kernel<true, false, 1024, MODE>;
-        return count ? render_kernel<false, true, 1024, MODE> : render_kernel<false, false, 1024, MODE>;
+        if (lds) return count ? render_kernel<true, true, 1024, MODE, TEX> : render_kernel<true, false, 1024, MODE, TEX>;
+        return count ? render_kernel<false, true, 1024, MODE, TEX> : render_kernel<false, false, 1024, MODE, TEX>;
     }
     if (block == 768) {
-        if (lds) return count ? render_kernel<true, true, 768, MODE> : render_kernel<true, false, 768, MODE>;
-        return count ? render_kernel<false, true, 768, MODE> : render_kernel<false, false, 768, MODE>;
+        if (lds) return count ? render_kernel<true, true, 768, MODE, TEX> : render_kernel<true, false, 768, MODE, TEX>;
+        return count ? render_kernel<false, true, 768, MODE, TEX> : render_kernel<false, false, 768, MODE, TEX>;
     }
     if (block == 512) {
-        if (lds) return count ? render_kernel<true, true, 512, MODE> : render_kernel<true, false, 512, MODE>;
-        return count ? render_kernel<false, true, 512, MODE> : render_kernel<false, false, 512, MODE>;
+        if (lds) return count ? render_kernel<true, true, 512, MODE, TEX> : render_kernel<true, false, 512, MODE, TEX>;
+        return count ? render_kernel<false, true, 512, MODE, TEX> : render_kernel<false, false, 512, MODE, TEX>;
     }
-    if (lds) return count ? render_kernel<true, true, 256, MODE> : render_kernel<true, false, 256, MODE>;
-    return count ? render_kernel<false, true, 256, MODE> : render_kernel<false, false, 256, MODE>;
+    if (lds) return count ? render_kernel<true, true, 256, MODE, TEX> : render_kernel<true, false, 256, MODE, TEX>;
+    return count ? render_kernel<false, true, 256, MODE, TEX> : render_kernel<false, false, 256, MODE, TEX>;
 }
-static render_fn pick_kernel(bool lds, bool count, int block, int mode) {
-    return mode == 0 ? pick_mode<0>(lds, count, block) : (mode == 1 ? pick_mode<1>(lds, count, block) : pick_mode<2>(lds, count, block));
+// tex: the scene has parameterised textures (otherwise the variant compiled without the texture call: no scratch, no VGPR spills)
+static render_fn pick_kernel(bool lds, bool count, int block, int mode, bool tex) {
+    if (tex) return mode == 0 ? pick_mode<0, true>(lds, count, block) : (mode == 1 ? pick_mode<1, true>(lds, count, block) : pick_mode<2, true>(lds, count, block));
+    return mode == 0 ? pick_mode<0, false>(lds, count, block) : (mode == 1 ? pick_mode<1, false>(lds, count, block) : pick_mode<2, false>(lds, count, block));
 }
 
 // Zeroes a launch's counters and queues and writes its camera: one tiny launch instead of a memset plus a copy from
@@ -444,7 +446,8 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
     p.accum = (int32_t *) d_accum;
     p.rgb = (uint8_t *) d_rgb;
 
-    render_fn fn = pick_kernel(lds, count, block, 0);
+    const bool tex = !h.texRecs.empty();
+    render_fn fn = pick_kernel(lds, count, block, 0, tex);
     const size_t ldsBytes = lds_need(h, lds, block, chunk);
     HIP_TRY(hipFuncSetAttribute((const void *) fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes));
     int perCu = 0;
@@ -506,7 +509,7 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
             p.queue_b = (unsigned long long *) (scr + 136);
             p.live_count = (unsigned int *) (scr + 144);
             p.total_waves = (uint32_t) (fullGrid * wavesPerBlock);
-            render_fn fa = pick_kernel(lds, count, block, 1), fb = pick_kernel(lds, count, block, 2);
+            render_fn fa = pick_kernel(lds, count, block, 1, tex), fb = pick_kernel(lds, count, block, 2, tex);
             // Unit sizes: pass A traces only 2k+1 samples per pixel, so its units are wide; pass B's largest unit is about a
             // sixteenth of a wave's share of the shard (measured best: 32 px at 1/2 frame, 16 at 1/4, 8 at 1/8 of config 3),
             // and shrinks towards the end of the cost-ordered list.

@@ -10,7 +10,7 @@ for b in re.split(r"remark: Function Name: ", txt)[1:]:
     if "render_kernel" not in name:
         continue
     g = lambda k: re.search(k + r": (\d+)", b).group(1)
-    m = re.search(r"render_kernelILb(\d)ELb(\d)ELi(\d+)ELi(\d)", name)
+    m = re.search(r"render_kernelILb(\d)ELb(\d)ELi(\d+)ELi(\d)ELb(\d)", name)
     scratch = g(r"ScratchSize \[bytes/lane\]")
-    print(f"LDS={m.group(1)} COUNT={m.group(2)} BLOCK={m.group(3):>4} MODE={m.group(4)}  SGPR {g('TotalSGPRs'):>3} VGPR {g('VGPRs'):>3} "
+    print(f"LDS={m.group(1)} COUNT={m.group(2)} BLOCK={m.group(3):>4} MODE={m.group(4)} TEX={m.group(5)}  SGPR {g('TotalSGPRs'):>3} VGPR {g('VGPRs'):>3} "
           f"scratch {scratch:>4} B  SGPR-spill {g('SGPRs Spill'):>3}  VGPR-spill {g('VGPRs Spill'):>3}")
