@@ -3,10 +3,12 @@
 // Takes the role of Scene.render / renderPixel / traceOnce / traceRay (Scene.fs:93-236) for one shard of image rows.
 //
 // Execution model:
-//   * One workgroup per CU-slot, scene image staged ONCE per workgroup into LDS (<= ~146 KiB at 1024 threads and 16-pixel units), then every
-//     WAVE is an independent worker pulling work units (runs of pixels) from a global queue, one atomic per unit.
-//   * Inside a unit the 64 lanes are path slots in one of three states (idle / walking the tree / walk finished); stages
-//     (refill, node loop, leaf tests, shade) run when enough lanes want them -- see run_items.
+//   * One workgroup per CU-slot, the tree, object geometry and meta words staged ONCE per workgroup into LDS (<= ~146 KiB at 1024
+//     threads and 16-pixel units; the material table stays in global memory), then every WAVE is an independent worker pulling
+//     work units (runs of pixels) from a global queue, one atomic per unit.
+//   * Inside a unit the 64 lanes are path slots in one of four states (idle / walking the tree / walk finished / waiting for
+//     the general reflection); stages (refill, general reflection, node loop, leaf tests, shade) run when enough lanes want
+//     them -- see Sched.
 //   * Adaptive sampling (Scene.fs:172-194): phase 1 traces 2k+1 samples of every pixel, splitting the byte sums after
 //     sample k; the wave compares the two integer means per pixel and ballot-compacts the pixels that must continue;
 //     phase 2 traces their remaining spp-2k-1 samples -- either right away on the same wave (fused mode) or in a second
