@@ -3,6 +3,7 @@ unsynchronised launches in flight, the caller's current device left alone, the t
 rt_render_frame (one process, several devices, one gather)."""
 import ctypes as C
 import dataclasses
+import os
 
 import numpy as np
 import pytest
@@ -93,7 +94,8 @@ def test_two_pass_unit_sizes_at_the_edge_of_the_lds(rt):
     for n in (490, 520, 550):  # 490, 520: 16-pixel units fit, 32 do not; 550: only the 256-thread block keeps the scene in LDS
         objs, cam, w, h = scenes.many_spheres(n=n, seed=6, spp=14, depth=8, pixels=480)  # 1.6 Mpx: pass B would ask for 32-pixel units
         s = rt.Scene.make(objs)
-        assert s.info()["lds_resident"] == 1, n
+        if not (os.environ.get("RTFS_BLOCK") or os.environ.get("RTFS_CHUNK")):  # (the stress knobs of conftest.py change what fits)
+            assert s.info()["lds_resident"] == 1, n
         try:
             rt.set_passes(1)
             fused = s.render_rows(w, h, cam, seed=9, counters=True)
