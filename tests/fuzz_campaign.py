@@ -1,7 +1,9 @@
 """Long-running fuzz of the HIP path against the oracle (run by hand on a GPU box: `python tests/fuzz_campaign.py [n_scenes] [first_seed]`;
 the pytest suite runs a 40-scene slice of the same idea).  Scenes: 3-60 bounded spheres of every style, overlapping and nested, now and
 then exact duplicates (equal t^2: the tie rule), negative radii, unbounded spheres and planes, cameras anywhere, bounce depths from 0.
-Each scene is rendered with the surface-area walk tree and with the reference's own tree; both must equal the oracle bit for bit."""
+Every sixth sphere or so carries a parameterised texture (checkered UV ramps, an image).  Each scene is rendered with the surface-area
+walk tree and with the reference's own tree, by the counting kernel variant (compiled node loop) and by the plain one (hand-written
+node loop, the one the bench times); all must equal the oracle bit for bit."""
 import dataclasses
 import os
 import sys
@@ -27,12 +29,21 @@ def scene(seed):
         return [S.LightSource(Tex(col())), S.LightSourceCap(col()), S.PureReflection(u(0, 1), Tex(col())), S.FuzzedReflection(u(0, 1), Tex(col()), u(0, 1)),
                 S.LambertReflection(u(0, 1), Tex(col())), S.Dielectric(u(0, 1), Tex(col()), u(0.7, 2.0), u(0, 1)), S.Glass(u(0.5, 1), Tex(col()), u(0.7, 2.0))][k]
 
+    PT = rt.ParameterisedTexture
+    img = scenes.checker_image(seed=seed % 7)
+
+    def textured(c, r):  # a LightSource / Lambert / Pure sphere whose texture is a function of the strike point (Texture.fs:50-67)
+        base = [PT.Checkered(PT.UvRamp("u", int(rng.integers(0, 256)), "v"), PT.UvRamp(int(rng.integers(0, 256)), "u", "v"), u(2.0, 80.0)),
+                PT.Image(img), PT.UvRamp("v", "u", int(rng.integers(0, 256)))][int(rng.integers(0, 3))]
+        tex = PT.toTexture((abs(r), c), base)
+        return [S.LightSource(tex), S.LambertReflection(u(0, 1), tex), S.PureReflection(u(0, 1), tex)][int(rng.integers(0, 3))]
+
     objs = []
     n = int(rng.integers(3, 61))
     spread = u(1.0, 6.0)
     for _ in range(n):
         c, r = P(u(-spread, spread), u(-1, 2.5), u(0, 2 * spread)), u(0.05, 1.5) * (-1.0 if rng.random() < 0.08 else 1.0)
-        objs.append(H.Sphere(rt.Sphere.make(style(), c, r)))
+        objs.append(H.Sphere(rt.Sphere.make(textured(c, r) if rng.random() < 0.15 else style(), c, r)))
         if rng.random() < 0.1:  # an exact duplicate with another material: equal t^2
             objs.append(H.Sphere(rt.Sphere.make(style(), c, r)))
     for _ in range(int(rng.integers(0, 3))):
@@ -68,7 +79,9 @@ def main():
                     res = s.render_rows(w, h, cam, seed=i, counters=True)
                 finally:
                     rt.set_passes(0)
+                plain = s.render_rows(w, h, cam, seed=i)
                 bad = (not np.array_equal(res.accum, acc)) or any(res.stats[k] != st[k] for k in ("rays", "prim_tests", "reflections", "samples"))
+                bad = bad or not np.array_equal(plain.accum, acc) or plain.stats["samples"] != st["samples"]
                 if tree == "reference":
                     bad = bad or res.stats["aabb_tests"] != st["aabb_tests"]
                 if bad:
