@@ -95,6 +95,7 @@ SIGNATURES = {
     "rt_dev_pixel_darken": (C.c_int, [C.c_int32, C.c_int32, _u8p, _dp, _u8p]),
     "rt_dev_reflection": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, _i32p, _dp, _u8p, _dp, _u32p, _i32p, _u8p, _dp]),
     "rt_dev_hit_object": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, _dp, _i32p, _dp, _u32p]),
+    "rt_dev_hit_object_lds": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, _dp, _i32p, _dp]),
     "rt_dev_trace_ray": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, _dp, _u32p, _u8p]),
     "rt_dev_texture_colour_at": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _u8p]),
     "rt_dev_arith": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp]),

@@ -515,6 +515,28 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
     }
 }
 
+// Stages the LDS part of the scene image (node, geo, meta) into the workgroup's LDS, 16 B per lane per trip, coalesced, and makes
+// the node links absolute LDS addresses: a walk position then IS the record's address (no add per visit).  Returns the bytes used.
+template <int BLOCK>
+RTD_INLINE uint32_t stage_scene(const RenderParams &p, unsigned char *smem) {
+    const uint32_t sceneBytes = p.off.lds_total;
+    const d2 *src = (const d2 *) p.scene_image;
+    RTD_AS3 d2 *dst = (RTD_AS3 d2 *) smem;
+    for (uint32_t i = threadIdx.x; i < sceneBytes / 16u; i += BLOCK) dst[i] = src[i];
+    __syncthreads();
+    RTD_AS3 unsigned char *nodes = (RTD_AS3 unsigned char *) smem + p.off.node;
+    const int first = (int) (uint32_t) (uintptr_t) nodes;
+    for (int i = threadIdx.x; i < p.off.n_nodes; i += BLOCK) {
+        RTD_AS3 i2 *lk = (RTD_AS3 i2 *) (nodes + i * RTD_NODE_BYTES + 96);
+        i2 v = *lk;
+        v.x += first; // a Leaf's RTD_LEAF flag (bit 30) is above every LDS address and survives the add
+        v.y += first;
+        *lk = v;
+    }
+    __syncthreads();
+    return sceneBytes;
+}
+
 // MODE 0: fused -- a unit's pixels go through phase 1, the adaptive decision and phase 2 on one wave.
 // MODE 1: pass A -- phase 1 and the decision for every pixel; pixels that continue are appended to `pairs` with the number of
 //         rays their 2k+1 samples took (a cost estimate), the others are final.
@@ -529,26 +551,8 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    uint32_t sceneBytes = 0;
-    if (LDS) { // stage the scene image: 16 B per lane per trip, coalesced
-        sceneBytes = p.off.lds_total;
-        const d2 *src = (const d2 *) p.scene_image;
-        RTD_AS3 d2 *dst = (RTD_AS3 d2 *) smem;
-        for (uint32_t i = threadIdx.x; i < sceneBytes / 16u; i += BLOCK) dst[i] = src[i];
-        __syncthreads();
-    }
+    const uint32_t sceneBytes = LDS ? stage_scene<BLOCK>(p, smem) : 0u;
     const SceneView<LDS> sc = make_view<LDS>(p, smem);
-    if (LDS) { // make the links absolute LDS addresses: a walk position then IS the record's address (no add per visit)
-        RTD_AS3 unsigned char *nodes = (RTD_AS3 unsigned char *) smem + p.off.node;
-        for (int i = threadIdx.x; i < p.off.n_nodes; i += BLOCK) {
-            RTD_AS3 i2 *lk = (RTD_AS3 i2 *) (nodes + i * RTD_NODE_BYTES + 96);
-            i2 v = *lk;
-            v.x += sc.first; // a Leaf's RTD_LEAF flag (bit 30) is above every LDS address and survives the add
-            v.y += sc.first;
-            *lk = v;
-        }
-        __syncthreads();
-    }
     const uint32_t P = (uint32_t) p.chunk;
     RTD_AS3 uint32_t *wv = (RTD_AS3 uint32_t *) (smem + sceneBytes) + (size_t) wave * (MODE == 1 ? RTD_WAVE_WORDS_A(P) : RTD_WAVE_WORDS(P));
     RTD_AS3 uint32_t *acc = wv;

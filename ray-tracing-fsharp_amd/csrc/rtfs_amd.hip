@@ -989,6 +989,33 @@ __global__ void k_hit_object(const RenderParams p, int n, const double *rays, in
     }
     if (counters) { counters[i * 2] = cnt.aabb; counters[i * 2 + 1] = cnt.prim; }
 }
+// Scene.hitObject as the render kernel's timed variant runs it: scene staged into LDS, the hand-written node loop
+// (node_loop_lds), leaf tests between its runs, the unbounded objects last.  One ray per lane, 1024 rays per workgroup.
+__global__ void __launch_bounds__(1024) k_hit_object_lds(const RenderParams p, int n, const double *rays, int32_t *hit, double *strike) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    (void) stage_scene<1024>(p, smem);
+    const SceneView<true> sc = make_view<true>(p, smem);
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const bool valid = i < n;
+    const double *r = rays + (size_t) (valid ? i : 0) * 6;
+    const V3 o = mk(r[0], r[1], r[2]), d = mk(r[3], r[4], r[5]);
+    Walk w;
+    walk_begin(w, sc.first);
+    if (!valid) w.off = sc.end;
+    WalkCtx c = walk_ctx(d, w);
+    for (;;) {
+        w.off = node_loop_lds(w.off, sc.end, 0, o, c); // until no lane of the wave is walking
+        if (__builtin_amdgcn_ballot_w64((w.off & RTD_LEAF) != 0) == 0ull) break;
+        if (w.off & RTD_LEAF) leaf_test<true>(sc, o, d, c, w);
+    }
+    Counters cnt; cnt.rays = cnt.aabb = cnt.prim = cnt.refl = 0;
+    unbounded_tests<true, false>(sc, o, d, w, cnt);
+    if (!valid) return;
+    hit[i] = w.best;
+    const V3 sp = walk(o, d, w.bestLen);
+    const double nanv = __builtin_nan("");
+    strike[i * 3] = w.best < 0 ? nanv : sp.x; strike[i * 3 + 1] = w.best < 0 ? nanv : sp.y; strike[i * 3 + 2] = w.best < 0 ? nanv : sp.z;
+}
 __global__ void k_trace_ray(const RenderParams p, int depth, int n, const double *rays, uint32_t *rng, uint8_t *col_out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1187,6 +1214,27 @@ int rt_dev_hit_object(int32_t device, const rt_scene *scene, int32_t n, const do
     for (int i = 0; i < n; ++i) if (hit_index[i] >= 0) hit_index[i] = scene->host.objToOrig[(size_t) hit_index[i]];
     if (strike) HIP_TRY(dsk.down(strike));
     if (counters) HIP_TRY(dc.down(counters));
+    return RT_OK;
+}
+
+int rt_dev_hit_object_lds(int32_t device, const rt_scene *scene, int32_t n, const double *rays, int32_t *hit_index, double *strike) {
+    if (!rays || !hit_index || !strike || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    RenderParams p;
+    DeviceGuard guard;
+    int rc = hook_scene_params(guard, device, scene, p);
+    if (rc != RT_OK) return rc;
+    const size_t ldsBytes = scene->host.off.lds_total;
+    if (ldsBytes > RT_LDS_BYTES) return fail(RT_ERR_UNSUPPORTED, "the scene does not fit the LDS");
+    DevBuf<double> dr, dsk; DevBuf<int32_t> dh;
+    HIP_TRY(dr.alloc((size_t) n * 6)); HIP_TRY(dh.alloc((size_t) n)); HIP_TRY(dsk.alloc((size_t) n * 3));
+    HIP_TRY(dr.up(rays));
+    HIP_TRY(hipFuncSetAttribute((const void *) k_hit_object_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes));
+    if (n) hipLaunchKernelGGL(k_hit_object_lds, dim3((unsigned) ((n + 1023) / 1024)), dim3(1024), ldsBytes, 0, p, n, dr.p, dh.p, dsk.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dh.down(hit_index));
+    for (int i = 0; i < n; ++i) if (hit_index[i] >= 0) hit_index[i] = scene->host.objToOrig[(size_t) hit_index[i]];
+    HIP_TRY(dsk.down(strike));
     return RT_OK;
 }
 

@@ -90,6 +90,15 @@ def hit_object(scene: Scene, rays, device=0):
     return hit, strike, cnt
 
 
+def hit_object_lds(scene: Scene, rays, device=0):
+    """Scene.hitObject through the timed kernel variant's route: scene in LDS, hand-written node loop."""
+    rays = _c(rays, np.float64).reshape(-1, 6)
+    n = len(rays)
+    hit, strike = np.zeros(n, np.int32), np.zeros((n, 3), np.float64)
+    check(lib.rt_dev_hit_object_lds(device, scene.handle, n, _f64(rays), _i32(hit), _f64(strike)))
+    return hit, strike
+
+
 def trace_ray(scene: Scene, bounce_depth, rays, rng_state, device=0):
     rays = _c(rays, np.float64).reshape(-1, 6)
     rng = _c(rng_state, np.uint32).reshape(-1, 4).copy()

@@ -169,6 +169,39 @@ def test_hit_object_indices_strikes_and_counters(rt, orc):
             assert c1[:, 0].sum() < c2[:, 0].sum() or len(objs) < 40
 
 
+def test_hit_object_through_the_hand_written_node_loop(rt, orc):
+    """The timed kernel variant walks the tree with node_loop_lds (assembly) on the LDS image; the hooks above run the compiled
+    C++ on the global image.  Same rays through both and through the oracle -- including what renders almost never produce:
+    axis-aligned directions (infinite inverse directions, NaN products), origins exactly on box planes and corners, rays along
+    box edges, and origins far outside the scene."""
+    rng = np.random.default_rng(2718)
+    for objs in (scenes.small_final()[0], scenes.all_materials()[0], scenes.many_spheres(n=300, seed=5)[0]):
+        s, o = _scene_pair(rt, orc, objs)
+        assert s.info()["lds_resident"] == 1
+        skip, prim, boxes = s.walk_tree()
+        n = 120000
+        rays = scenes.random_rays(n, 99, origin_scale=5.0)
+        k = 20000
+        rays[:k, 3:] = np.eye(3)[rng.integers(0, 3, k)] * rng.choice([-1.0, 1.0], size=(k, 1))       # axis-aligned
+        two = np.eye(3)[rng.integers(0, 3, k)] + np.eye(3)[rng.integers(0, 3, k)] * rng.choice([-1.0, 1.0], size=(k, 1))
+        ok = np.linalg.norm(two, axis=1) > 0.5
+        two[~ok] = [1.0, 1.0, 0.0]
+        rays[k:2 * k, 3:] = two / np.linalg.norm(two, axis=1, keepdims=True)                              # in a coordinate plane: one infinite inverse
+        if len(boxes):
+            b = boxes[rng.integers(0, len(boxes), 3 * k)]                                               # (minx,maxx,miny,maxy,minz,maxz)
+            corner = np.stack([b[:, 0 + rng.integers(0, 2)], b[:, 2 + rng.integers(0, 2)], b[:, 4 + rng.integers(0, 2)]], axis=1)
+            rays[:k, :3] = corner[:k]                                                                   # axis-aligned ray from a box corner
+            rays[2 * k:3 * k, :3] = corner[k:2 * k]                                                     # any direction from a box corner
+            rays[3 * k:4 * k, 1] = b[2 * k:, 2]                                                         # origin on a box's y-min plane (the floor of the small spheres)
+        rays[4 * k:5 * k, :3] *= 1e6                                                                    # far away
+        h1, s1 = rt.hooks.hit_object_lds(s, rays)
+        h0, s0, _ = rt.hooks.hit_object(s, rays)
+        h2, s2, _ = o.hit_object(rays)
+        assert np.array_equal(h1, h2) and _same_f64(s1, s2)
+        assert np.array_equal(h0, h2) and _same_f64(s0, s2)
+        assert 0.05 < np.mean(h2 >= 0) <= 1.0
+
+
 def test_reflection_every_style(rt, orc):
     objs, *_ = scenes.all_materials()
     s, o = _scene_pair(rt, orc, objs)
