@@ -93,7 +93,7 @@ enum rt_texture_kind {
 };
 
 enum rt_ramp_source { RT_RAMP_CONST = 0, RT_RAMP_U = 1, RT_RAMP_V = 2 };
-enum rt_walk_tree { RT_WALK_TREE_SAH = 0, RT_WALK_TREE_REFERENCE = 1 };
+enum rt_walk_tree { RT_WALK_TREE_SAH = 0, RT_WALK_TREE_REFERENCE = 1, RT_WALK_TREE_TUNED = 2 /* reported after rt_scene_tune; not a creation option */ };
 
 typedef struct rt_texture {
     uint32_t kind;          /* rt_texture_kind */
@@ -164,6 +164,31 @@ int rt_scene_get_tree(const rt_scene *scene, int32_t *skip, int32_t *prim, doubl
  * RT_WALK_TREE_REFERENCE; under RT_WALK_TREE_SAH another binary tree over the same Leaf boxes, every Branch box again the
  * exact union of the Leaf boxes below it. */
 int rt_scene_get_walk_tree(const rt_scene *scene, int32_t *skip, int32_t *prim, double *boxes);
+
+/* ---- Tuning the walk tree to a camera (no counterpart in the reference: BoundingBoxTree.make knows no rays) ----------
+ * Renders a PROBE with the scene as it stands -- 16 image rows spread over the frame, through the counting kernel, which logs a
+ * thinned-out sample of the rays it traces (a few ten thousand: origin and direction) -- and rebuilds the tree the device walks
+ * from them: split costs are the number of probe rays that hit a candidate box (not its area), and Branch boxes that nearly
+ * every arriving ray hits are not tested at all (their children take their place; csrc/rt_scene.h "thinning").  Every pixel
+ * stays the same bit for bit, as under rt_set_walk_tree and for the same reason; what changes is aabb_tests (final scene:
+ * 23.8 -> about 17 per ray) and the frame time.  rt_scene_get_walk_tree then reports an n-ary tree in the same pre-order/skip
+ * form, rt_scene_get_info.walk_tree = RT_WALK_TREE_TUNED, n_nodes shrinks.  The probe is deterministic (which rays are logged
+ * depends on their random streams only, and the log is sorted), so the same call yields the same tree.
+ * A scene that walks the reference's own tree (RT_WALK_TREE_REFERENCE, or fewer than 3 bounded spheres, or non-finite boxes)
+ * is left alone: tuned = 0.  Must not run concurrently with renders of the same scene: it replaces the device images (after
+ * waiting for the devices that hold one).  Typical use: once after rt_scene_create, with the camera and image size of the
+ * frames to come; the cost is a few milliseconds of GPU time plus the host build (final scene: ~30 ms). */
+typedef struct rt_tune_info {
+    uint32_t struct_size;      /* sizeof(rt_tune_info) as the caller compiled it */
+    int32_t  tuned;            /* 1: the walk tree was replaced */
+    int32_t  probe_rows;       /* image rows rendered for the probe */
+    int32_t  probe_rays;       /* rays the build used */
+    int32_t  nodes_before, nodes_after;
+    double   box_tests_before, box_tests_after; /* BoundingBox.hits calls per probe ray, counted on the host */
+    double   probe_ms, build_ms;
+} rt_tune_info;
+int rt_scene_tune(rt_scene *scene, const rt_camera *camera, int32_t max_width_coord, int32_t max_height_coord, uint64_t seed,
+                  int32_t device, rt_tune_info *info /* may be NULL */);
 
 /* ---- Render (Scene.render, Scene.fs:196-236) ---------------------------------------------------- */
 typedef struct rt_stats {
@@ -268,7 +293,7 @@ int rt_device_count(void);         /* 0 when no HIP device is visible (never an 
 const char *rt_last_error(void);   /* thread-local message of the last failing call */
 int rt_abi_version(void);
 /* sizeof of the ABI structs as compiled: 0 rt_hittable, 1 rt_texture, 2 rt_camera, 3 rt_scene_info, 4 rt_stats,
- * 5 rt_render_options, 6 rt_scene_options (bindings check their mirrors). */
+ * 5 rt_render_options, 6 rt_scene_options, 7 rt_tune_info (bindings check their mirrors). */
 size_t rt_abi_sizeof(int which);
 /* Byte offset of field number `field` (declaration order, from 0) of struct `which` (numbering of rt_abi_sizeof), or
  * (size_t)-1 past the last field: a binding in another language asserts its own layout against these at start-up

@@ -58,6 +58,10 @@ struct RenderParams {
     unsigned int *live_count;      // number of pairs / list entries (device side)
     unsigned long long *queue_b;   // next unassigned list entry
     uint32_t total_waves;          // waves of the grid (guided unit sizes in pass B)
+    // rt_scene_tune's probe (counting variant only): every ray whose stream-state hash has `ray_log_mask` clear is appended
+    double *ray_log;               // [ray_log_cap][6]: origin, direction; null outside a probe
+    unsigned int *ray_log_count;   // rays that wanted a slot (may exceed the capacity: the probe is then repeated more thinly)
+    uint32_t ray_log_cap, ray_log_mask;
 };
 
 // Per-wave LDS scratch (in 4-byte words), P = pixels per work unit:
@@ -165,6 +169,18 @@ struct Sched {
         ended = false; result = 0;
     }
 
+    // the probe of rt_scene_tune: a thinned-out log of the rays as they start (which rays: a hash of the ray's stream state, so
+    // the logged SET does not depend on scheduling; the host sorts it)
+    RTD_INLINE void log_ray() {
+        if (p.ray_log != nullptr && ((((rng.x ^ rng.w) * 0x9E3779B1u) >> 8) & p.ray_log_mask) == 0u) {
+            const unsigned int at = atomicAdd(p.ray_log_count, 1u);
+            if (at < p.ray_log_cap) {
+                double *r = p.ray_log + 6u * (size_t) at;
+                r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
+            }
+        }
+    }
+
     // a new (pixel, sample) item: Scene.traceOnce's ray (Scene.fs:129-150)
     RTD_INLINE bool start_item(uint64_t pkey, uint32_t sample, int row, int col, uint32_t slot_off) {
         rng = stream_for(pkey, sample);
@@ -176,7 +192,7 @@ struct Sched {
         if (camera_ray(*cp, row, col, rng, o, d)) {
             st = L_WALK;
             walk_begin(w, sc.first);
-            if (COUNT) cnt.rays++;
+            if (COUNT) { cnt.rays++; log_ray(); }
             return true;
         }
         return false; // Scene.fs:144's ValueOption.get would throw; the sample counts as Black (adds nothing)
@@ -230,7 +246,7 @@ struct Sched {
         else {
             st = L_WALK;
             walk_begin(w, sc.first);
-            if (COUNT) cnt.rays++;
+            if (COUNT) { cnt.rays++; log_ray(); }
         }
     }
 

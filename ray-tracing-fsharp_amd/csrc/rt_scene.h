@@ -11,6 +11,8 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 namespace rth {
@@ -32,6 +34,7 @@ static inline double volume(const Box &b) { return (b.mx[0] - b.mn[0]) * (b.mx[1
 struct FlatTree {
     std::vector<int32_t> skip, prim; // prim = object-table index of a Leaf, -1 for a Branch
     std::vector<Box> box;
+    std::vector<double> hits;        // probe rays that hit the box (only while a tree is being tuned)
     int depth = 0;
 };
 
@@ -106,21 +109,44 @@ static inline double half_area(const Box &b) {
     for (int a = 0; a < 3; ++a) { d[a] = b.mx[a] - b.mn[a]; if (!(d[a] > 0.0)) d[a] = 0.0; } // inverted (negative-radius) boxes count as empty
     return d[0] * d[1] + d[1] * d[2] + d[0] * d[2];
 }
+// Probe rays (rt_scene_tune): rays of a small render with the scene's camera, as the device logged them.  With them the split
+// cost of a candidate box is the NUMBER OF PROBE RAYS THAT HIT IT instead of its area -- rays of this renderer start on surfaces
+// inside the scene, for which area is a poor predictor -- and the finished tree is then thinned (collapse_tree below).
+struct ProbeRay { double o[3], inv[3]; };
+// BoundingBox.hits (BoundingBox.fs:30-94) for the tuning statistics (no result depends on it; the walk itself is rt_device.h's)
+static inline bool probe_hits(const ProbeRay &r, const Box &b) {
+    double tMin = -HUGE_VAL, tMax = HUGE_VAL;
+    for (int a = 0; a < 3; ++a) {
+        double t0 = (b.mn[a] - r.o[a]) * r.inv[a], t1 = (b.mx[a] - r.o[a]) * r.inv[a];
+        if (r.inv[a] < 0.0) { const double tmp = t1; t1 = t0; t0 = tmp; }
+        tMin = t0 > tMin ? t0 : tMin;
+        tMax = t1 < tMax ? t1 : tMax;
+        if (a < 2 && (tMax < tMin || 0.0 >= tMax)) return false;
+    }
+    return tMax >= tMin && tMax >= 0.0;
+}
+
 class SahBuilder {
   public:
-    SahBuilder(const std::vector<Box> &objBoxes, FlatTree &out) : ob(objBoxes), t(out) {}
+    SahBuilder(const std::vector<Box> &objBoxes, FlatTree &out, const std::vector<ProbeRay> *probe = nullptr) : ob(objBoxes), t(out), rays(probe) {}
     void build() {
         std::vector<int32_t> ids(ob.size());
         for (size_t j = 0; j < ob.size(); ++j) ids[j] = (int32_t) j;
         suffix.resize(ob.size() + 1);
-        go(ids.data(), ids.size(), 1);
+        std::vector<uint32_t> all;
+        if (rays) { all.resize(rays->size()); for (size_t i = 0; i < all.size(); ++i) all[i] = (uint32_t) i; }
+        go(ids.data(), ids.size(), 1, all, rays ? (double) rays->size() : 0.0, 0.0);
     }
 
   private:
     const std::vector<Box> &ob;
     FlatTree &t;
+    const std::vector<ProbeRay> *rays;
     std::vector<double> suffix;
+    std::vector<Box> pre, suf;          // boxes of ids[0, k) and ids[k, n) of the axis being swept (probe mode)
+    std::vector<uint32_t> cntP, cntS;
     static const size_t kSweepMax = 4096; // above this a node is split on 32 centroid bins per axis instead of a full sweep
+    static const size_t kProbeMin = 32;   // fewer probe rays than this in a box: its subtree is split by area
     double centroid2(int32_t id, int axis) const { return ob[(size_t) id].mn[axis] + ob[(size_t) id].mx[axis]; }
     void sort_axis(int32_t *ids, size_t n, int axis) const {
         std::sort(ids, ids + n, [&](int32_t a, int32_t b) {
@@ -128,7 +154,12 @@ class SahBuilder {
             return ca < cb || (ca == cb && a < b);
         });
     }
-    void go(int32_t *ids, size_t n, int depth) {
+    // A subtree of m leaves has 2m-1 boxes, but a ray that enters it visits far fewer than all of them: m^0.8 was the best
+    // exponent on the final scene (scripts/tree_collapse.py: 20.1 visits per ray with exponent 1, 18.7 with 0.8, 18.9 with 0.6).
+    static double subtree_weight(size_t leaves) { return std::pow((double) (2 * leaves - 1), 0.8); }
+    // `idx`: the probe rays that hit the parent's box (all of them at the root); parentHits / parentArea: the estimate this
+    // node's own count is scaled from once the rays have run out
+    void go(int32_t *ids, size_t n, int depth, const std::vector<uint32_t> &idx, double parentHits, double parentArea) {
         if (depth > t.depth) t.depth = depth;
         Box all = ob[(size_t) ids[0]];
         for (size_t i = 1; i < n; ++i) all = merge_two(all, ob[(size_t) ids[i]]);
@@ -136,13 +167,50 @@ class SahBuilder {
         t.skip.push_back(0);
         t.prim.push_back(n == 1 ? ids[0] : -1);
         t.box.push_back(all);
+        std::vector<uint32_t> hidx; // the probe rays that hit this box
+        double myHits = 0.0;
+        if (rays) {
+            if (idx.size() >= kProbeMin || depth == 1) {
+                hidx.reserve(idx.size());
+                for (uint32_t r : idx) if (probe_hits((*rays)[r], all)) hidx.push_back(r);
+                myHits = (double) hidx.size();
+            } else myHits = parentArea > 0.0 ? parentHits * std::min(1.0, half_area(all) / parentArea) : parentHits;
+            t.hits.push_back(myHits);
+        }
+        const bool probe = rays && hidx.size() >= kProbeMin && n <= kSweepMax;
         if (n > 1) {
             size_t k = n / 2;
             int bestAxis = -1;
             if (depth < 48) { // a degenerate input cannot make the recursion deeper than this: below, halve by centroid order
                 double bestCost = 0.0;
                 for (int axis = 0; axis < 3; ++axis) {
-                    if (n <= kSweepMax) {
+                    if (probe) {
+                        // pre[k] grows and suf[k] shrinks with k, and a ray that hits a box hits every box around it: per ray
+                        // two binary searches give the first prefix and the last suffix it hits
+                        sort_axis(ids, n, axis);
+                        pre.resize(n + 1); suf.resize(n + 1); cntP.assign(n + 1, 0u); cntS.assign(n + 1, 0u);
+                        pre[1] = ob[(size_t) ids[0]];
+                        for (size_t i = 2; i < n; ++i) pre[i] = merge_two(pre[i - 1], ob[(size_t) ids[i - 1]]);
+                        suf[n - 1] = ob[(size_t) ids[n - 1]];
+                        for (size_t i = n - 1; i-- > 1;) suf[i] = merge_two(suf[i + 1], ob[(size_t) ids[i]]);
+                        for (uint32_t r : hidx) {
+                            const ProbeRay &ray = (*rays)[r];
+                            size_t lo = 1, hi = n; // first k in [1, n) with pre[k] hit, n if none
+                            while (lo < hi) { const size_t mid = (lo + hi) / 2; if (probe_hits(ray, pre[mid])) hi = mid; else lo = mid + 1; }
+                            cntP[lo]++;
+                            lo = 0; hi = n - 1; // last k in [1, n) with suf[k] hit, 0 if none
+                            while (lo < hi) { const size_t mid = (lo + hi + 1) / 2; if (probe_hits(ray, suf[mid])) lo = mid; else hi = mid - 1; }
+                            cntS[lo]++;
+                        }
+                        uint64_t hs = 0;
+                        for (size_t i = n - 1; i >= 1; --i) { hs += cntS[i]; suffix[i] = (double) hs; }
+                        uint64_t hp = 0;
+                        for (size_t i = 1; i < n; ++i) { // left = ids[0, i), right = ids[i, n)
+                            hp += cntP[i];
+                            const double cost = ((double) hp + 1.0) * subtree_weight(i) + (suffix[i] + 1.0) * subtree_weight(n - i);
+                            if (bestAxis < 0 || cost < bestCost) { bestCost = cost; bestAxis = axis; k = i; }
+                        }
+                    } else if (n <= kSweepMax) {
                         sort_axis(ids, n, axis);
                         Box acc = ob[(size_t) ids[n - 1]];
                         for (size_t i = n - 1; i >= 1; --i) { if (i < n - 1) acc = merge_two(acc, ob[(size_t) ids[i]]); suffix[i] = half_area(acc); }
@@ -186,10 +254,72 @@ class SahBuilder {
                      const double ca = centroid2(a, bestAxis), cb = centroid2(b, bestAxis);
                      return ca < cb || (ca == cb && a < b);
                  });
-            go(ids, k, depth + 1);
-            go(ids + k, n - k, depth + 1);
+            const double myArea = half_area(all);
+            go(ids, k, depth + 1, hidx, myHits, myArea);
+            go(ids + k, n - k, depth + 1, hidx, myHits, myArea);
         }
         t.skip[me] = (int32_t) t.skip.size();
+    }
+};
+
+// ---- thinning the walk tree -------------------------------------------------------------------------------------------
+// NOT testing a Branch box changes no result either: the walk then goes on to the Branch's children as if the box had been hit,
+// and a ray that misses the box misses everything below it anyway, Leaf boxes included.  It pays where nearly every ray that
+// gets as far as the Branch hits it -- one test saved for most rays, a few wasted on the children for the rest.  With H(N) = the
+// number of probe rays that hit box N (a property of the box alone, by the monotonicity above) the visits of ANY choice of
+// tested Branches are  sum over tested N of H(nearest tested box above N), so the best choice is a small dynamic programme over
+// (node, nearest tested box above).  In the flat pre-order layout an untested Branch simply disappears: its children take its
+// place among their grandparent's children, and the on-hit / on-miss links of rt_device.h need nothing new.
+// On the final scene: 22.2 box tests per probe ray for the surface-area tree, 17.3 after thinning it, 15.5 for the probe-count
+// build thinned (scripts/tree_collapse.py).
+struct TreeThinner {
+    const FlatTree &b;
+    const double total; // probe rays
+    std::unordered_map<uint64_t, std::pair<double, bool>> memo;
+    static const size_t kExactMax = 200000; // nodes; above this the choice is made greedily, top down
+    TreeThinner(const FlatTree &binary, double totalRays) : b(binary), total(totalRays) {}
+    double w(int64_t anc) const { return anc < 0 ? total + 1.0 : b.hits[(size_t) anc] + 1.0; }
+    // expected visits inside i's subtree and whether i's box is tested, when the nearest tested box above i is `anc` (-1: none)
+    std::pair<double, bool> best(int32_t i, int64_t anc) {
+        if (b.prim[(size_t) i] >= 0) return {w(anc), true}; // a Leaf box is always tested: Scene.bestCandidate's own test
+        if (b.skip.size() > kExactMax) return {0.0, !(w(i) >= 0.5 * w(anc))};
+        const uint64_t key = ((uint64_t) (uint32_t) i << 32) | (uint64_t) (uint32_t) (anc + 1);
+        auto it = memo.find(key);
+        if (it != memo.end()) return it->second;
+        double cT = w(anc), cS = 0.0;
+        for (int32_t k = i + 1; k < b.skip[(size_t) i]; k = b.skip[(size_t) k]) { cT += best(k, i).first; cS += best(k, anc).first; }
+        const std::pair<double, bool> r = cT <= cS ? std::make_pair(cT, true) : std::make_pair(cS, false);
+        memo.emplace(key, r);
+        return r;
+    }
+    void emit(int32_t i, int64_t anc, int depth, FlatTree &out) {
+        const bool tested = best(i, anc).second;
+        size_t me = 0;
+        if (tested) {
+            me = out.skip.size();
+            out.skip.push_back(0); out.prim.push_back(b.prim[(size_t) i]); out.box.push_back(b.box[(size_t) i]); out.hits.push_back(b.hits[(size_t) i]);
+            if (depth > out.depth) out.depth = depth;
+        }
+        for (int32_t k = i + 1; k < b.skip[(size_t) i]; k = b.skip[(size_t) k]) emit(k, tested ? i : anc, tested ? depth + 1 : depth, out);
+        if (tested) out.skip[me] = (int32_t) out.skip.size();
+    }
+    // the expected box tests per probe ray of a tree as it stands (every box of it tested)
+    static double visits_per_ray(const FlatTree &t, double totalRays) {
+        if (t.skip.empty() || !(totalRays > 0.0)) return 0.0;
+        // a node is visited by the rays that hit its parent; walk the pre-order with a stack of (end, hits)
+        std::vector<std::pair<int32_t, double>> up;
+        double sum = 0.0;
+        for (size_t i = 0; i < t.skip.size(); ++i) {
+            while (!up.empty() && (int32_t) i >= up.back().first) up.pop_back();
+            sum += up.empty() ? totalRays : up.back().second;
+            if (t.prim[i] < 0) up.emplace_back(t.skip[i], t.hits[i]);
+        }
+        return sum / totalRays;
+    }
+    FlatTree run() {
+        FlatTree out;
+        if (!b.skip.empty()) emit(0, -1, 1, out);
+        return out;
     }
 };
 
@@ -201,8 +331,10 @@ struct HostScene {
     std::vector<int32_t> objToOrig; // object-table index -> index in `hittables`
     std::vector<int32_t> origToObj;
     FlatTree tree;     // BoundingBoxTree.make's tree; prim = object-table index (= the leaf's depth-first rank)
-    FlatTree walkTree; // what the device image holds: `tree` itself or the surface-area build over the same leaves
+    FlatTree walkTree; // what the device image holds: `tree` itself, the surface-area build over the same leaves, or a tuned tree
     int walkKind = RT_WALK_TREE_REFERENCE;
+    std::vector<Box> leafBoxes; // by object-table index (= rank), for rt_scene_tune
+    size_t nBounded = 0, nUnbounded = 0;
     std::vector<unsigned char> image;
     rtd::SceneOffsets off{};
 };
@@ -211,6 +343,7 @@ static inline uint32_t pack_rgb(const uint8_t rgb[3]) { return (uint32_t) rgb[0]
 
 static inline size_t align16(size_t v) { return (v + 15u) & ~(size_t) 15u; }
 
+static void encode_image(HostScene &s);
 // Returns an empty string on success, otherwise the message for rt_last_error().
 static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture *tex, size_t ntex, int walk_kind, HostScene &s, int &status) {
     status = RT_ERR_INVALID_ARGUMENT;
@@ -306,12 +439,22 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
     for (size_t j = 0; j < nobj; ++j) s.origToObj[(size_t) s.objToOrig[j]] = (int32_t) j;
 
     s.walkKind = (walk_kind == RT_WALK_TREE_REFERENCE || !finite || nb < 3) ? RT_WALK_TREE_REFERENCE : RT_WALK_TREE_SAH;
+    s.leafBoxes.assign(nb, Box{});
+    for (size_t j = 0; j < nb; ++j) s.leafBoxes[(size_t) rankOf[j]] = boxes[j];
+    s.nBounded = nb; s.nUnbounded = nu;
     if (s.walkKind == RT_WALK_TREE_SAH) {
-        std::vector<Box> byRank(nb);
-        for (size_t j = 0; j < nb; ++j) byRank[(size_t) rankOf[j]] = boxes[j];
         s.walkTree = FlatTree{};
-        SahBuilder(byRank, s.walkTree).build();
+        SahBuilder(s.leafBoxes, s.walkTree).build();
     } else s.walkTree = s.tree;
+    encode_image(s);
+    status = RT_OK;
+    return std::string();
+}
+
+// The device image of s.walkTree and the object table (layout: rt_device.h).  Called again when the walk tree changes.
+static void encode_image(HostScene &s) {
+    const rt_hittable *h = s.hittables.data();
+    const size_t nb = s.nBounded, nu = s.nUnbounded, nobj = nb + nu;
     const FlatTree &wt = s.walkTree;
     const size_t nn = wt.skip.size();
 
@@ -378,8 +521,31 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
         pmeta[j * 2] = (int32_t) m0;
         pmeta[j * 2 + 1] = (int32_t) (pack_rgb(o.rgb) | ((uint32_t) (o.texture + 1) << 24));
     }
-    status = RT_OK;
-    return std::string();
+}
+
+// rt_scene_tune's host half: the walk tree rebuilt from probe rays (split costs from ray counts, then thinned) and the image
+// encoded again.  Returns false (and changes nothing) for a scene that walks the reference's own tree.
+struct TuneResult { double visitsBefore = 0.0, visitsAfter = 0.0; int32_t nodesBefore = 0, nodesAfter = 0; };
+static bool tune_walk_tree(HostScene &s, const std::vector<ProbeRay> &rays, TuneResult &r) {
+    if (s.walkKind == RT_WALK_TREE_REFERENCE || s.nBounded < 3 || rays.empty()) return false;
+    const double total = (double) rays.size();
+    {   // what the tree walked so far costs these rays
+        const FlatTree &cur = s.walkTree;
+        uint64_t visits = 0;
+        for (const ProbeRay &ray : rays)
+            for (size_t i = 0; i < cur.skip.size();) { ++visits; i = probe_hits(ray, cur.box[i]) ? i + 1 : (size_t) cur.skip[i]; }
+        r.visitsBefore = (double) visits / total;
+        r.nodesBefore = (int32_t) cur.skip.size();
+    }
+    FlatTree binary;
+    SahBuilder(s.leafBoxes, binary, &rays).build();
+    s.walkTree = TreeThinner(binary, total).run();
+    s.walkKind = RT_WALK_TREE_TUNED;
+    r.visitsAfter = TreeThinner::visits_per_ray(s.walkTree, total);
+    r.nodesAfter = (int32_t) s.walkTree.skip.size();
+    s.walkTree.hits.clear();
+    encode_image(s);
+    return true;
 }
 
 // ---- Camera.makeBasic (Camera.fs:34-59) with Plane.makeNormalTo' (Plane.fs:22-38) and Plane.basis (Plane.fs:82-97) ----

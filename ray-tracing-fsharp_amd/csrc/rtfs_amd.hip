@@ -207,6 +207,7 @@ size_t rt_abi_sizeof(int which) {
     case 4: return sizeof(rt_stats);
     case 5: return sizeof(rt_render_options);
     case 6: return sizeof(rt_scene_options);
+    case 7: return sizeof(rt_tune_info);
     default: return 0;
     }
 }
@@ -233,6 +234,9 @@ size_t rt_abi_offsetof(int which, int field) {
                     F(rt_render_options, blocks_per_cu), F(rt_render_options, yield_lanes), F(rt_render_options, refill_lanes),
                     F(rt_render_options, passes), F(rt_render_options, park_lanes))
     case 6: RT_OFFS(rt_scene_options, F(rt_scene_options, struct_size), F(rt_scene_options, walk_tree))
+    case 7: RT_OFFS(rt_tune_info, F(rt_tune_info, struct_size), F(rt_tune_info, tuned), F(rt_tune_info, probe_rows), F(rt_tune_info, probe_rays),
+                    F(rt_tune_info, nodes_before), F(rt_tune_info, nodes_after), F(rt_tune_info, box_tests_before), F(rt_tune_info, box_tests_after),
+                    F(rt_tune_info, probe_ms), F(rt_tune_info, build_ms))
     default: return (size_t) -1;
     }
 #undef F
@@ -369,6 +373,8 @@ static int check_geometry(const rt_camera *camera, int32_t max_w, int32_t max_h,
 
 // What a launch leaves behind when its statistics are wanted: events around the kernels and the launch's scratch, which
 // then stays allocated until the counters have been read.
+struct RayLog { double *rays; unsigned int *count; uint32_t cap, mask; }; // rt_scene_tune's probe (RenderParams::ray_log)
+
 struct Pending {
     hipEvent_t a = nullptr, b = nullptr;
     unsigned char *scr = nullptr;
@@ -390,7 +396,7 @@ struct Pending {
 // and its scratch is kept in `pd` for collect_stats.
 static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t max_w, int32_t max_h, uint64_t seed, int32_t device,
                          int32_t row_first, int32_t row_stride, int32_t n_rows, uint32_t flags, void *d_accum, void *d_rgb, void *stream,
-                         const rt_render_options *options, bool want_stats, Pending &pd) {
+                         const rt_render_options *options, bool want_stats, Pending &pd, const RayLog *log = nullptr) {
     rt_stats *stats = want_stats ? (rt_stats *) 1 : nullptr; // only tested for NULL below
     if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
     int rc = check_geometry(camera, max_w, max_h, row_first, row_stride, n_rows);
@@ -445,6 +451,7 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
     p.refill_lanes = set.refill ? set.refill : RTD_REFILL_DEFAULT;
     p.accum = (int32_t *) d_accum;
     p.rgb = (uint8_t *) d_rgb;
+    if (log) { p.ray_log = log->rays; p.ray_log_count = log->count; p.ray_log_cap = log->cap; p.ray_log_mask = log->mask; }
 
     const bool tex = !h.texRecs.empty();
     render_fn fn = pick_kernel(lds, count, block, 0, tex);
@@ -593,6 +600,97 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
                      int32_t row_first, int32_t row_stride, int32_t n_rows, uint32_t flags, void *d_accum, void *d_rgb, void *stream,
                      rt_stats *stats) {
     return rt_render_device_ex(scene, camera, max_w, max_h, seed, device, row_first, row_stride, n_rows, flags, d_accum, d_rgb, stream, nullptr, stats);
+}
+
+int rt_scene_tune(rt_scene *scene, const rt_camera *camera, int32_t max_w, int32_t max_h, uint64_t seed, int32_t device, rt_tune_info *info) {
+    rt_tune_info out{};
+    auto report = [&]() {
+        if (!info) return;
+        const uint32_t sz = info->struct_size;
+        memcpy(info, &out, sz < sizeof(out) ? sz : sizeof(out));
+        info->struct_size = sz;
+    };
+    if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (info && info->struct_size < sizeof(uint32_t)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_tune_info.struct_size is not set");
+    int rc = check_geometry(camera, max_w, max_h, 0, 1, 0);
+    if (rc != RT_OK) return rc;
+    rth::HostScene &h = scene->host;
+    out.nodes_before = out.nodes_after = h.off.n_nodes;
+    if (h.walkKind == RT_WALK_TREE_REFERENCE || h.nBounded < 3) { report(); return RT_OK; }
+    DeviceGuard guard;
+    rc = guard.enter(device);
+    if (rc != RT_OK) return rc;
+
+    // ---- the probe: 16 rows spread over the frame, rays logged 1 in 2^k ----
+    const int rows = 2 * max_h + 1, cols = 2 * max_w + 1;
+    const int nProbe = rows < 16 ? rows : 16, stride = rows / nProbe, first = stride / 2;
+    const uint32_t cap = 1u << 18, want = 32768u;
+    const double upper = (double) nProbe * (double) cols * (double) camera->samples_per_pixel * 4.0; // ~4 rays per sample
+    int k = 0;
+    while (k < 20 && upper / (double) (1u << k) > (double) (cap / 2u)) ++k;
+    struct Bufs {
+        int32_t *accum = nullptr; double *rays = nullptr; unsigned int *count = nullptr;
+        ~Bufs() { (void) hipFree(accum); (void) hipFree(rays); (void) hipFree(count); }
+    } b;
+    HIP_TRY(hipMalloc((void **) &b.accum, (size_t) nProbe * (size_t) cols * 16u));
+    HIP_TRY(hipMalloc((void **) &b.rays, (size_t) cap * 48u));
+    HIP_TRY(hipMalloc((void **) &b.count, sizeof(unsigned int)));
+    unsigned int logged = 0;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        HIP_TRY(hipMemset(b.count, 0, sizeof(unsigned int)));
+        const RayLog log{b.rays, b.count, cap, (1u << k) - 1u};
+        Pending pd;
+        rc = launch_render(scene, camera, max_w, max_h, seed, device, first, stride, nProbe, RT_RENDER_COUNTERS, b.accum, nullptr, nullptr, nullptr, true, pd, &log);
+        if (rc != RT_OK) return rc;
+        rt_stats st;
+        rc = collect_stats(pd, &st);
+        if (rc != RT_OK) return rc;
+        out.probe_ms += st.kernel_ms;
+        HIP_TRY(hipMemcpy(&logged, b.count, sizeof(logged), hipMemcpyDeviceToHost));
+        if (logged > cap && k < 20) { k += 2; continue; }           // too many: log more thinly
+        if (logged < want / 8u && k > 0) { k = k > 3 ? k - 3 : 0; continue; } // too few: log more densely
+        break;
+    }
+    out.probe_rows = nProbe;
+    if (logged > cap) logged = cap;
+    if (logged == 0) { report(); return RT_OK; }
+
+    // ---- host: sort the log (its order depends on scheduling, its content does not), thin it to `want` rays, rebuild ----
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Raw { double v[6]; };
+    std::vector<Raw> raw(logged);
+    HIP_TRY(hipMemcpy(raw.data(), b.rays, (size_t) logged * sizeof(Raw), hipMemcpyDeviceToHost));
+    std::sort(raw.begin(), raw.end(), [](const Raw &x, const Raw &y) { return memcmp(&x, &y, sizeof(Raw)) < 0; });
+    std::vector<rth::ProbeRay> rays;
+    const size_t n = raw.size() < want ? raw.size() : (size_t) want;
+    rays.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Raw &r = raw[i * raw.size() / n];
+        rth::ProbeRay pr;
+        for (int a = 0; a < 3; ++a) { pr.o[a] = r.v[a]; pr.inv[a] = 1.0 / r.v[3 + a]; }
+        rays.push_back(pr);
+    }
+    rth::TuneResult tr;
+    {
+        std::lock_guard<std::mutex> lock(scene->mu);
+        if (!rth::tune_walk_tree(h, rays, tr)) { report(); return RT_OK; }
+        for (auto &kv : scene->dev) { // the devices that hold a copy get the new image, once they have finished what they were doing
+            HIP_TRY(hipSetDevice(kv.first));
+            HIP_TRY(hipDeviceSynchronize());
+            (void) hipFree(kv.second.image);
+            kv.second.image = nullptr;
+            HIP_TRY(hipMalloc((void **) &kv.second.image, h.image.size()));
+            HIP_TRY(hipMemcpy(kv.second.image, h.image.data(), h.image.size(), hipMemcpyHostToDevice));
+        }
+        HIP_TRY(hipSetDevice(device));
+    }
+    out.tuned = 1;
+    out.probe_rays = (int32_t) rays.size();
+    out.nodes_before = tr.nodesBefore; out.nodes_after = tr.nodesAfter;
+    out.box_tests_before = tr.visitsBefore; out.box_tests_after = tr.visitsAfter;
+    out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    report();
+    return RT_OK;
 }
 
 int rt_render(const rt_scene *scene, const rt_camera *camera, int32_t max_w, int32_t max_h, uint64_t seed, int32_t device,
