@@ -154,6 +154,7 @@ def main():
                     help="nccl (= RCCL) is the product path; gloo stages the gather through host memory and lets several ranks share one GPU (rehearsal only)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--no-tune", action="store_true", help="walk the surface-area tree as built, without rt_scene_tune's probe")
     args = ap.parse_args()
 
     import torch
@@ -198,6 +199,9 @@ def main():
         objs, cam, w, h = rt.sample_images.config5_mixed(earth, seed=args.seed, depth=args.depth)
         label = "config 5: final scene + earth-textured sphere + Dielectric sphere + mirror InfinitePlane (recipe"
     scene = rt.Scene.make(objs)
+    # Scene preparation, once per scene and camera, outside the timed steps like Scene.make itself: the walk tree rebuilt from the
+    # rays of a 16-row probe render (rt_scene_tune).  Every rank probes the same rows of the whole frame, so all walk the same tree.
+    tune = None if args.no_tune else scene.tune(w, h, cam, seed=args.seed, device=local_rank)
     rows, cols = 2 * h + 1, 2 * w + 1
     first, stride, n = rtd.shard_rows(rows, rank, world)
     n_pad = (rows + world - 1) // world
@@ -228,7 +232,7 @@ def main():
                                      counters=True, want_stats=True)
     torch.cuda.synchronize(dev)
     if not torch.equal(check, local) or any(st_ref[k] != st[k] for k in ("rays", "prim_tests", "reflections", "samples", "pixels_early")):
-        raise SystemExit("walking the reference's tree and the surface-area tree gave different results")
+        raise SystemExit("walking the reference's own tree and the tree of this run gave different results")
     del check, ref_scene
     step()  # untimed, whatever --warmup says: first launch of the timed kernel variant, stream-ordered pool set-up, and (N>1)
             # the first gather, which sets up RCCL's peer-to-peer connections over xGMI
@@ -277,6 +281,9 @@ def main():
         rank_bytes = algorithmic_bytes(st)
         rank_flops = algorithmic_flops(st)
         achieved_tf = rank_flops / (kernel_ms * 1e-3) / 1e12
+        # the same with the box tests of the reference's own tree ("N_* must equal the oracle's counters"): the work
+        # the reference's algorithm does for this frame, of which the walked tree skips a part
+        ref_flops = algorithmic_flops({**st, "aabb_tests": st_ref["aabb_tests"]})
         ceiling_tf, ceiling_src = measured_issue_ceiling()
         info = scene.info()
         traffic, src = profiled_traffic() if (world == 1 and args.workload == "c3") else (None, None)  # the committed PMC passes are of config 3
@@ -293,10 +300,12 @@ def main():
             "backend": args.backend if world > 1 else None,
             "config": {"workload": f"{label}, seed {args.seed}), "
                                    f"maxW={w} maxH={h} -> {cols}x{rows} px, {cam.SamplesPerPixel} spp adaptive, {cam.BounceDepth} bounces",
-                       "spheres_bounded": info["n_bounded"], "unbounded": info["n_unbounded"], "tree_nodes": info["n_nodes"],
+                       "spheres_bounded": info["n_bounded"], "unbounded": info["n_unbounded"], "tree_nodes": info["n_nodes"], "walk_tree_nodes": info["walk_tree_nodes"],
                        "lds_resident_scene": bool(info["lds_resident"]),
-                       "walk_tree": "surface-area build over the reference's leaf boxes (same hits; DESIGN.md 'Walk tree')" if info["walk_tree"] == 0
-                                    else "BoundingBoxTree.make's own", "sharding": f"rows interleaved over {world} rank(s), one gather"},
+                       "walk_tree": ("surface-area build over the reference's leaf boxes (same hits; DESIGN.md 'Walk tree')",
+                                     "BoundingBoxTree.make's own",
+                                     "rebuilt from the rays of a probe render and thinned (rt_scene_tune; same hits; DESIGN.md 'Walk tree')")[info["walk_tree"]],
+                       "tune": tune, "sharding": f"rows interleaved over {world} rank(s), one gather"},
             "job": {**job, "pixels": rows * cols, "wall_s_per_frame": round(ms_per_step / 1e3, 4),
                     "ray_sphere_tests_per_s": round(job["prim_tests"] / (ms_per_step * 1e-3), 1),
                     "aabb_tests_per_s": round(job["aabb_tests"] / (ms_per_step * 1e-3), 1),
@@ -311,12 +320,15 @@ def main():
                          "measured_issue_source": ceiling_src,
                          "traffic": traffic, "traffic_source": traffic_src, "physical_from_same_profile": physical,
                          "kernel": "rtd::render_kernel", "kernel_ms": round(kernel_ms, 3), "algorithmic_flops_per_launch": rank_flops,
+                         "reference_tree_equiv": {"flops_per_launch": ref_flops, "tflops": round(ref_flops / (kernel_ms * 1e-3) / 1e12, 3),
+                                                  "note": "the box tests BoundingBoxTree.make's own tree would have cost (the oracle's count), / the same "
+                                                          "kernel time: work the reference's algorithm does per frame -- NOT executed here, not a roofline fraction"},
                          "limited_by": limited,
                          "algorithmic_hbm_equiv": {"bytes_per_launch": rank_bytes, "gb_per_s": round(rank_bytes / (kernel_ms * 1e-3) / 1e9, 1),
                                                    "of_hbm_peak": round(rank_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 3),
                                                    "note": "SURVEY.md 8(d)'s scene bytes the algorithm touches (56 B per box test, ...), served by LDS -- "
                                                            "not HBM traffic and not a roofline fraction; `traffic` is the physical HBM byte count per launch"},
-                         "note": "achieved = algorithmic FP64 flops (18 per box test, 17 per sphere test, 3 per ray) / mean kernel time"},
+                         "note": "achieved = FP64 flops of the tests EXECUTED (18 per box test of the walked tree, 17 per sphere test, 3 per ray) / mean kernel time"},
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(objs, cam, w, h, args.seed, args.cpu_seconds)

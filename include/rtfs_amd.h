@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
@@ -131,7 +131,7 @@ typedef struct rt_scene rt_scene;
 typedef struct rt_scene_info {
     int32_t n_bounded;      /* Hittable.Sphere count (leaves of the tree) */
     int32_t n_unbounded;    /* UnboundedSphere + InfinitePlane count, original order kept (Array.partition) */
-    int32_t n_nodes;        /* BoundingBoxTree nodes, leaves included (2*n_bounded-1) */
+    int32_t n_nodes;        /* BoundingBoxTree nodes, leaves included (2*n_bounded-1): the size of rt_scene_get_tree's arrays */
     int32_t tree_depth;     /* of BoundingBoxTree.make's tree (what rt_scene_get_tree reports) */
     int32_t n_textures;
     int32_t lds_resident;   /* 1 if the flattened scene fits the 160 KiB LDS image and the LDS kernel is used */
@@ -139,6 +139,9 @@ typedef struct rt_scene_info {
     int32_t walk_tree_depth;
     int64_t scene_bytes;    /* bytes of the flattened device image (without texels) */
     int64_t texel_bytes;
+    int32_t walk_tree_nodes; /* nodes of the tree the device image holds: the size of rt_scene_get_walk_tree's arrays (= n_nodes
+                                until rt_scene_tune thins the tree) */
+    int32_t reserved;
 } rt_scene_info;
 
 /* Scene.make (Scene.fs:15-28): partitions bounded/unbounded, builds the BoundingBoxTree on the host,
@@ -189,6 +192,9 @@ typedef struct rt_tune_info {
 } rt_tune_info;
 int rt_scene_tune(rt_scene *scene, const rt_camera *camera, int32_t max_width_coord, int32_t max_height_coord, uint64_t seed,
                   int32_t device, rt_tune_info *info /* may be NULL */);
+/* The host half alone, with the caller's own probe: rays[n_rays][6] = origin xyz, direction xyz (at most 32768 of them are used,
+ * evenly spaced).  Touches a GPU only to replace device copies of the image that already exist.  probe_rows and probe_ms stay 0. */
+int rt_scene_tune_rays(rt_scene *scene, const double *rays, size_t n_rays, rt_tune_info *info /* may be NULL */);
 
 /* ---- Render (Scene.render, Scene.fs:196-236) ---------------------------------------------------- */
 typedef struct rt_stats {

@@ -2,7 +2,7 @@
 tests/test_abi.py checks sizes against the values compiled into the library (rt_abi_sizeof)."""
 import ctypes as C
 
-RT_ABI_VERSION = 3
+RT_ABI_VERSION = 4
 
 RT_OK, RT_ERR_INVALID_ARGUMENT, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_IO = range(6)
 
@@ -16,7 +16,7 @@ RT_PLANE_LIGHT_SOURCE, RT_PLANE_PURE_REFLECTION, RT_PLANE_LAMBERT_REFLECTION, RT
 # rt_texture_kind
 RT_TEXTURE_COLOUR, RT_TEXTURE_CHECKERED, RT_TEXTURE_IMAGE, RT_TEXTURE_UV_RAMP = range(4)
 RT_RAMP_CONST, RT_RAMP_U, RT_RAMP_V = range(3)
-RT_WALK_TREE_SAH, RT_WALK_TREE_REFERENCE = range(2)
+RT_WALK_TREE_SAH, RT_WALK_TREE_REFERENCE, RT_WALK_TREE_TUNED = range(3)
 
 RT_RENDER_COUNTERS = 1
 RT_GATHER_AUTO, RT_GATHER_RCCL, RT_GATHER_PEER, RT_GATHER_HOST = range(4)
@@ -60,7 +60,7 @@ class rt_scene_info(C.Structure):
     _fields_ = [
         ("n_bounded", C.c_int32), ("n_unbounded", C.c_int32), ("n_nodes", C.c_int32), ("tree_depth", C.c_int32),
         ("n_textures", C.c_int32), ("lds_resident", C.c_int32), ("walk_tree", C.c_int32), ("walk_tree_depth", C.c_int32),
-        ("scene_bytes", C.c_int64), ("texel_bytes", C.c_int64),
+        ("scene_bytes", C.c_int64), ("texel_bytes", C.c_int64), ("walk_tree_nodes", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -92,5 +92,16 @@ class rt_scene_options(C.Structure):
         super().__init__(struct_size=C.sizeof(rt_scene_options), walk_tree=walk_tree)
 
 
+class rt_tune_info(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("tuned", C.c_int32), ("probe_rows", C.c_int32), ("probe_rays", C.c_int32),
+        ("nodes_before", C.c_int32), ("nodes_after", C.c_int32), ("box_tests_before", C.c_double), ("box_tests_after", C.c_double),
+        ("probe_ms", C.c_double), ("build_ms", C.c_double),
+    ]
+
+    def __init__(self):
+        super().__init__(struct_size=C.sizeof(rt_tune_info))
+
+
 # numbering of rt_abi_sizeof / rt_abi_offsetof
-ABI_STRUCTS = (rt_hittable, rt_texture, rt_camera, rt_scene_info, rt_stats, rt_render_options, rt_scene_options)
+ABI_STRUCTS = (rt_hittable, rt_texture, rt_camera, rt_scene_info, rt_stats, rt_render_options, rt_scene_options, rt_tune_info)

@@ -227,7 +227,7 @@ size_t rt_abi_offsetof(int which, int field) {
                     F(rt_camera, focal_length), F(rt_camera, samples_per_pixel), F(rt_camera, bounce_depth))
     case 3: RT_OFFS(rt_scene_info, F(rt_scene_info, n_bounded), F(rt_scene_info, n_unbounded), F(rt_scene_info, n_nodes), F(rt_scene_info, tree_depth),
                     F(rt_scene_info, n_textures), F(rt_scene_info, lds_resident), F(rt_scene_info, walk_tree), F(rt_scene_info, walk_tree_depth),
-                    F(rt_scene_info, scene_bytes), F(rt_scene_info, texel_bytes))
+                    F(rt_scene_info, scene_bytes), F(rt_scene_info, texel_bytes), F(rt_scene_info, walk_tree_nodes), F(rt_scene_info, reserved))
     case 4: RT_OFFS(rt_stats, F(rt_stats, rays), F(rt_stats, aabb_tests), F(rt_stats, prim_tests), F(rt_stats, reflections), F(rt_stats, samples),
                     F(rt_stats, pixels), F(rt_stats, pixels_early), F(rt_stats, kernel_ms), F(rt_stats, total_ms))
     case 5: RT_OFFS(rt_render_options, F(rt_render_options, struct_size), F(rt_render_options, block_threads), F(rt_render_options, chunk_pixels),
@@ -326,7 +326,9 @@ int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
     const rth::HostScene &h = s->host;
     out->n_bounded = h.off.n_bounded;
     out->n_unbounded = h.off.n_unbounded;
-    out->n_nodes = h.off.n_nodes;
+    out->n_nodes = (int32_t) h.tree.skip.size();
+    out->walk_tree_nodes = h.off.n_nodes;
+    out->reserved = 0;
     out->tree_depth = h.tree.depth;
     out->walk_tree = h.walkKind;
     out->walk_tree_depth = h.walkTree.depth;
@@ -602,6 +604,50 @@ int rt_render_device(const rt_scene *scene, const rt_camera *camera, int32_t max
     return rt_render_device_ex(scene, camera, max_w, max_h, seed, device, row_first, row_stride, n_rows, flags, d_accum, d_rgb, stream, nullptr, stats);
 }
 
+} // extern "C"
+
+// The host half of tuning: at most 32768 of `raw` (evenly spaced) become the probe; the walk tree is rebuilt and every device that
+// holds a copy of the image gets the new one, once it has finished what it was doing.
+struct RawRay { double v[6]; };
+static int apply_tune(rt_scene *scene, const std::vector<RawRay> &raw, rt_tune_info &out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t want = 32768;
+    std::vector<rth::ProbeRay> rays;
+    const size_t n = raw.size() < want ? raw.size() : want;
+    rays.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        const RawRay &r = raw[i * raw.size() / n];
+        rth::ProbeRay pr;
+        for (int a = 0; a < 3; ++a) { pr.o[a] = r.v[a]; pr.inv[a] = 1.0 / r.v[3 + a]; }
+        rays.push_back(pr);
+    }
+    rth::TuneResult tr;
+    std::lock_guard<std::mutex> lock(scene->mu);
+    rth::HostScene &h = scene->host;
+    if (!rth::tune_walk_tree(h, rays, tr)) return RT_OK; // a reference-tree scene, or no rays: left as it is
+    if (!scene->dev.empty()) {
+        int prev = -1;
+        HIP_TRY(hipGetDevice(&prev));
+        for (auto &kv : scene->dev) {
+            HIP_TRY(hipSetDevice(kv.first));
+            HIP_TRY(hipDeviceSynchronize());
+            (void) hipFree(kv.second.image);
+            kv.second.image = nullptr;
+            HIP_TRY(hipMalloc((void **) &kv.second.image, h.image.size()));
+            HIP_TRY(hipMemcpy(kv.second.image, h.image.data(), h.image.size(), hipMemcpyHostToDevice));
+        }
+        HIP_TRY(hipSetDevice(prev));
+    }
+    out.tuned = 1;
+    out.probe_rays = (int32_t) rays.size();
+    out.nodes_before = tr.nodesBefore; out.nodes_after = tr.nodesAfter;
+    out.box_tests_before = tr.visitsBefore; out.box_tests_after = tr.visitsAfter;
+    out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
+extern "C" {
+
 int rt_scene_tune(rt_scene *scene, const rt_camera *camera, int32_t max_w, int32_t max_h, uint64_t seed, int32_t device, rt_tune_info *info) {
     rt_tune_info out{};
     auto report = [&]() {
@@ -636,7 +682,7 @@ int rt_scene_tune(rt_scene *scene, const rt_camera *camera, int32_t max_w, int32
     HIP_TRY(hipMalloc((void **) &b.rays, (size_t) cap * 48u));
     HIP_TRY(hipMalloc((void **) &b.count, sizeof(unsigned int)));
     unsigned int logged = 0;
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    for (int attempt = 0; attempt < 6; ++attempt) {
         HIP_TRY(hipMemset(b.count, 0, sizeof(unsigned int)));
         const RayLog log{b.rays, b.count, cap, (1u << k) - 1u};
         Pending pd;
@@ -654,43 +700,30 @@ int rt_scene_tune(rt_scene *scene, const rt_camera *camera, int32_t max_w, int32
     out.probe_rows = nProbe;
     if (logged > cap) logged = cap;
     if (logged == 0) { report(); return RT_OK; }
+    // ---- host: sort the log (its order depends on scheduling, its content does not) and rebuild ----
+    std::vector<RawRay> raw(logged);
+    HIP_TRY(hipMemcpy(raw.data(), b.rays, (size_t) logged * sizeof(RawRay), hipMemcpyDeviceToHost));
+    std::sort(raw.begin(), raw.end(), [](const RawRay &x, const RawRay &y) { return memcmp(&x, &y, sizeof(RawRay)) < 0; });
+    rc = apply_tune(scene, raw, out);
+    if (rc == RT_OK) report();
+    return rc;
+}
 
-    // ---- host: sort the log (its order depends on scheduling, its content does not), thin it to `want` rays, rebuild ----
-    const auto t0 = std::chrono::steady_clock::now();
-    struct Raw { double v[6]; };
-    std::vector<Raw> raw(logged);
-    HIP_TRY(hipMemcpy(raw.data(), b.rays, (size_t) logged * sizeof(Raw), hipMemcpyDeviceToHost));
-    std::sort(raw.begin(), raw.end(), [](const Raw &x, const Raw &y) { return memcmp(&x, &y, sizeof(Raw)) < 0; });
-    std::vector<rth::ProbeRay> rays;
-    const size_t n = raw.size() < want ? raw.size() : (size_t) want;
-    rays.reserve(n);
-    for (size_t i = 0; i < n; ++i) {
-        const Raw &r = raw[i * raw.size() / n];
-        rth::ProbeRay pr;
-        for (int a = 0; a < 3; ++a) { pr.o[a] = r.v[a]; pr.inv[a] = 1.0 / r.v[3 + a]; }
-        rays.push_back(pr);
+int rt_scene_tune_rays(rt_scene *scene, const double *rays, size_t n_rays, rt_tune_info *info) {
+    rt_tune_info out{};
+    if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (n_rays > 0 && !rays) return fail(RT_ERR_INVALID_ARGUMENT, "rays is NULL");
+    if (info && info->struct_size < sizeof(uint32_t)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_tune_info.struct_size is not set");
+    out.nodes_before = out.nodes_after = scene->host.off.n_nodes;
+    std::vector<RawRay> raw(n_rays);
+    if (n_rays) memcpy(raw.data(), rays, n_rays * sizeof(RawRay));
+    const int rc = apply_tune(scene, raw, out);
+    if (rc == RT_OK && info) {
+        const uint32_t sz = info->struct_size;
+        memcpy(info, &out, sz < sizeof(out) ? sz : sizeof(out));
+        info->struct_size = sz;
     }
-    rth::TuneResult tr;
-    {
-        std::lock_guard<std::mutex> lock(scene->mu);
-        if (!rth::tune_walk_tree(h, rays, tr)) { report(); return RT_OK; }
-        for (auto &kv : scene->dev) { // the devices that hold a copy get the new image, once they have finished what they were doing
-            HIP_TRY(hipSetDevice(kv.first));
-            HIP_TRY(hipDeviceSynchronize());
-            (void) hipFree(kv.second.image);
-            kv.second.image = nullptr;
-            HIP_TRY(hipMalloc((void **) &kv.second.image, h.image.size()));
-            HIP_TRY(hipMemcpy(kv.second.image, h.image.data(), h.image.size(), hipMemcpyHostToDevice));
-        }
-        HIP_TRY(hipSetDevice(device));
-    }
-    out.tuned = 1;
-    out.probe_rays = (int32_t) rays.size();
-    out.nodes_before = tr.nodesBefore; out.nodes_after = tr.nodesAfter;
-    out.box_tests_before = tr.visitsBefore; out.box_tests_after = tr.visitsAfter;
-    out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    report();
-    return RT_OK;
+    return rc;
 }
 
 int rt_render(const rt_scene *scene, const rt_camera *camera, int32_t max_w, int32_t max_h, uint64_t seed, int32_t device,

@@ -58,6 +58,13 @@ int main(int argc, char **argv) {
                       << " walkDepth=" << si.walk_tree_depth << "\n";
             return 0;
         }
+        // frames of more than ~1e8 samples repay the tenth of a second rt_scene_tune takes (same pixels, fewer box tests per ray)
+        const double samples = (double) (2 * def.maxWidthCoord + 1) * (double) (2 * def.maxHeightCoord + 1) * (double) def.camera.SamplesPerPixel;
+        if (samples >= 1e8) {
+            const rt_tune_info ti = scene->tune(def.maxWidthCoord, def.maxHeightCoord, def.camera, seed, device);
+            if (ti.tuned) std::fprintf(stderr, "walk tree tuned: %.1f -> %.1f box tests per probe ray, %d -> %d nodes, %.0f ms\n", ti.box_tests_before,
+                                       ti.box_tests_after, ti.nodes_before, ti.nodes_after, ti.probe_ms + ti.build_ms);
+        }
         auto res = Scene::render(tick, [](const std::string &) {}, def.maxWidthCoord, def.maxHeightCoord, def.camera, scene, seed, device);
         Image &image = res.second;
         const std::vector<uint8_t> &rows = image.render(); // forces the render on the GPU

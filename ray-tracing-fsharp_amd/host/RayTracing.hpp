@@ -269,6 +269,16 @@ class Scene {
         return {(double) rowsIter, Image(rowsIter, colsIter, force)};
     }
 
+    // rt_scene_tune (no counterpart in the reference): the walk tree rebuilt from the rays of a small probe render with this camera;
+    // same pixels, about a third fewer box tests per ray.  Worth its ~0.1 s for any frame of more than a few hundred million samples.
+    rt_tune_info tune(int maxWidthCoord, int maxHeightCoord, const Camera &camera, uint64_t seed = 0, int device = 0) {
+        rt_tune_info info{};
+        info.struct_size = sizeof(info);
+        rt_camera cam = camera.toAbi();
+        check(rt_scene_tune(h_, &cam, maxWidthCoord, maxHeightCoord, seed, device, &info));
+        return info;
+    }
+
     rt_scene *handle() const { return h_; }
     rt_stats lastStats{};
 

@@ -433,10 +433,23 @@ class Scene:
 
     def walk_tree(self):
         """The tree the device image holds (rt_set_walk_tree): same arrays as tree()."""
-        n = self.info()["n_nodes"]
+        n = self.info()["walk_tree_nodes"]
         skip = np.zeros(n, np.int32); prim = np.zeros(n, np.int32); boxes = np.zeros((n, 6), np.float64)
         check(lib.rt_scene_get_walk_tree(self._h, _i32(skip), _i32(prim), _f64(boxes)))
         return skip, prim, boxes
+
+    def tune(self, maxWidthCoord: int, maxHeightCoord: int, camera: Camera, *, seed: int = 0, device: int = 0) -> dict:
+        """rt_scene_tune: the walk tree rebuilt from the rays of a small probe render with this camera (same pixels, fewer box tests)."""
+        info = A.rt_tune_info()
+        check(lib.rt_scene_tune(self._h, C.byref(camera.to_abi()), maxWidthCoord, maxHeightCoord, seed, device, C.byref(info)))
+        return {n: getattr(info, n) for n, _ in info._fields_ if n != "struct_size"}
+
+    def tune_rays(self, rays: np.ndarray) -> dict:
+        """rt_scene_tune_rays: the host half of tune() with the caller's own probe rays [n, 6] (origin, direction)."""
+        r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        info = A.rt_tune_info()
+        check(lib.rt_scene_tune_rays(self._h, _f64(r), r.shape[0], C.byref(info)))
+        return {n: getattr(info, n) for n, _ in info._fields_ if n != "struct_size"}
 
     def render_rows(self, maxWidthCoord: int, maxHeightCoord: int, camera: Camera, *, seed: int = 0, device: int = 0,
                     row_first: int = 0, row_stride: int = 1, n_rows: Optional[int] = None, counters: bool = False) -> RenderResult:

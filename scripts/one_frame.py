@@ -22,6 +22,7 @@ ap.add_argument("--park", type=int, default=0, help="park pool entries per wave;
 ap.add_argument("--passes", type=int, default=0)
 ap.add_argument("--yield-lanes", type=int, default=0)
 ap.add_argument("--refill-lanes", type=int, default=0)
+ap.add_argument("--no-tune", action="store_true", help="skip rt_scene_tune")
 a = ap.parse_args()
 rt.set_launch_config(a.block, a.chunk)
 rt.set_park(a.park)
@@ -29,6 +30,8 @@ rt.set_passes(a.passes)
 rt.set_schedule(a.yield_lanes, a.refill_lanes)
 objs, cam, w, h = rt.sample_images.config3_final(spp=a.spp, depth=a.depth, pixels=a.pixels)
 scene = rt.Scene.make(objs)
+if not a.no_tune:
+    scene.tune(w, h, cam, seed=2024)
 rows, cols = 2 * h + 1, 2 * w + 1
 local = torch.zeros((rows, cols, 4), dtype=torch.int32, device="cuda:0")
 for _ in range(a.launches):

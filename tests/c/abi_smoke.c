@@ -40,17 +40,19 @@ int main(void) {
         static const int hittable[][2] = {{4, 1}, {4, 1}, {8, 3}, {8, 3}, {8, 1}, {8, 1}, {8, 1}, {8, 1}, {8, 1}, {1, 3}, {1, 1}, {4, 1}};
         static const int texture[][2] = {{4, 1}, {1, 3}, {1, 3}, {1, 2}, {4, 1}, {4, 1}, {8, 1}, {4, 1}, {4, 1}, {8, 1}, {8, 3}, {8, 1}};
         static const int camera[][2] = {{8, 3}, {8, 3}, {8, 3}, {8, 3}, {8, 3}, {8, 3}, {8, 1}, {8, 1}, {8, 1}, {4, 1}, {4, 1}};
-        static const int info[][2] = {{4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {8, 1}, {8, 1}};
+        static const int info[][2] = {{4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {8, 1}, {8, 1}, {4, 1}, {4, 1}};
         static const int stats[][2] = {{8, 1}, {8, 1}, {8, 1}, {8, 1}, {8, 1}, {8, 1}, {8, 1}, {8, 1}, {8, 1}};
         static const int ropt[][2] = {{4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}};
         static const int sopt[][2] = {{4, 1}, {4, 1}};
+        static const int tune[][2] = {{4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {4, 1}, {8, 1}, {8, 1}, {8, 1}, {8, 1}};
         CHECK(sequential_layout_matches(0, hittable, 12) && sizeof(rt_hittable) == 104 && rt_abi_offsetof(0, 11) == 100);
         CHECK(sequential_layout_matches(1, texture, 12));
         CHECK(sequential_layout_matches(2, camera, 11));
-        CHECK(sequential_layout_matches(3, info, 10) && sequential_layout_matches(4, stats, 9));
+        CHECK(sequential_layout_matches(3, info, 12) && sequential_layout_matches(4, stats, 9));
         CHECK(sequential_layout_matches(5, ropt, 8) && sequential_layout_matches(6, sopt, 2));
         CHECK(rt_abi_offsetof(0, 3) == offsetof(rt_hittable, normal) && rt_abi_offsetof(1, 9) == offsetof(rt_texture, texels));
-        CHECK(rt_abi_offsetof(7, 0) == (size_t) -1);
+        CHECK(rt_abi_sizeof(7) == sizeof(rt_tune_info) && sequential_layout_matches(7, tune, 10));
+        CHECK(rt_abi_offsetof(8, 0) == (size_t) -1);
     }
 
     /* Camera.makeBasic for the final scene */

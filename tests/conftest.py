@@ -22,6 +22,16 @@ def rt():
         m.set_walk_tree(os.environ["RTFS_TREE"])
     if os.environ.get("RTFS_BLOCK") or os.environ.get("RTFS_CHUNK"):
         m.set_launch_config(int(os.environ.get("RTFS_BLOCK", "0")), int(os.environ.get("RTFS_CHUNK", "0")))
+    if os.environ.get("RTFS_TUNE") == "1":  # every scene is tuned (rt_scene_tune) with the camera of its first render
+        plain = m.Scene.render_rows
+
+        def tuned_first(self, maxWidthCoord, maxHeightCoord, camera, *, seed=0, device=0, **kw):
+            if not getattr(self, "_tuned", False):
+                self._tuned = True
+                self.tune(maxWidthCoord, maxHeightCoord, camera, seed=seed, device=device)
+            return plain(self, maxWidthCoord, maxHeightCoord, camera, seed=seed, device=device, **kw)
+
+        m.Scene.render_rows = tuned_first
     return m
 
 

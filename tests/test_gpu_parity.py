@@ -474,7 +474,8 @@ def test_full_size_config3_properties(rt):
     if rt.get_walk_tree() == "reference":
         assert a.stats["aabb_tests"] == 98205213022  # BoundingBoxTree.make's tree: 28.0 box tests per ray
     else:
-        assert 0.7 * 98205213022 < a.stats["aabb_tests"] < 0.92 * 98205213022  # the surface-area tree over the same leaves
+        lo = 0.5 if os.environ.get("RTFS_TUNE") == "1" else 0.7  # the surface-area tree over the same leaves; thinner still when tuned
+        assert lo * 98205213022 < a.stats["aabb_tests"] < 0.92 * 98205213022
         rt.set_walk_tree("reference")
         try:
             c = rt.Scene.make(objs).render_rows(w, h, cam, seed=2024, counters=True)
