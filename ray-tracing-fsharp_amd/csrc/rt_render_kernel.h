@@ -118,7 +118,7 @@ struct StageStats { // wave-uniform, COUNT variant only
 };
 
 #define RTD_YIELD_DEFAULT 44
-#define RTD_REFILL_DEFAULT 12
+#define RTD_REFILL_DEFAULT 16
 
 // ---- the lane scheduler shared by every render mode ------------------------------------------------------------------------
 // Every lane of a wave is a path slot in one of four states: IDLE (wants a new item), WALK (somewhere in the tree walk of its

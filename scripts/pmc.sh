@@ -16,10 +16,10 @@ run ic SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLIC
 run fetch FETCH_SIZE GRBM_GUI_ACTIVE
 run write WRITE_SIZE
 for d in sq1 sq2 sq3 ic fetch write; do f=$(ls $OUT/$d/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python - "$f" <<'PY'
-import csv, sys, collections
+import csv, sys, collections, re
 acc = collections.defaultdict(float)
 for r in csv.DictReader(open(sys.argv[1])):
-    if "render_kernel" in r["Kernel_Name"]:
+    if "render_kernel" in r["Kernel_Name"] and not re.search(r"render_kernel<(true|false), true", r["Kernel_Name"]):  # not the counting variant (rt_scene_tune's probe)
         acc[r["Counter_Name"]] += float(r["Counter_Value"])
 for k, v in acc.items():
     print(f"{k},{v:.0f}")
