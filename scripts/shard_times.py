@@ -6,6 +6,8 @@ import ray_tracing_fsharp_amd as rt
 from ray_tracing_fsharp_amd import distributed as rtd
 objs, cam, w, h = rt.sample_images.config3_final()
 scene = rt.Scene.make(objs)
+if "--no-tune" not in sys.argv:
+    print("tune:", scene.tune(w, h, cam, seed=2024))
 rows, cols = 2*h+1, 2*w+1
 base = None
 ref = {}
