@@ -173,8 +173,9 @@ class SahBuilder {
             if (idx.size() >= kProbeMin || depth == 1) {
                 hidx.reserve(idx.size());
                 for (uint32_t r : idx) if (probe_hits((*rays)[r], all)) hidx.push_back(r);
-                myHits = (double) hidx.size();
-            } else myHits = parentArea > 0.0 ? parentHits * std::min(1.0, half_area(all) / parentArea) : parentHits;
+                myHits = hidx.empty() ? 1.0 : (double) hidx.size(); // a box no probe ray hit still counts as one ray's worth: the area estimates below scale from it
+            } else // the rays have run out: from here down the counts are the parent's, scaled by area
+                myHits = parentArea > 0.0 ? parentHits * std::min(1.0, half_area(all) / parentArea) : parentHits;
             t.hits.push_back(myHits);
         }
         const bool probe = rays && hidx.size() >= kProbeMin && n <= kSweepMax;
@@ -278,7 +279,9 @@ struct TreeThinner {
     std::unordered_map<uint64_t, std::pair<double, bool>> memo;
     static const size_t kExactMax = 200000; // nodes; above this the choice is made greedily, top down
     TreeThinner(const FlatTree &binary, double totalRays) : b(binary), total(totalRays) {}
-    double w(int64_t anc) const { return anc < 0 ? total + 1.0 : b.hits[(size_t) anc] + 1.0; }
+    // counts below SahBuilder::kProbeMin were replaced by area-scaled estimates there, so no further smoothing is needed (the
+    // small constant only keeps a box nobody hit from costing exactly nothing)
+    double w(int64_t anc) const { return anc < 0 ? total + 1e-9 : b.hits[(size_t) anc] + 1e-9; }
     // expected visits inside i's subtree and whether i's box is tested, when the nearest tested box above i is `anc` (-1: none)
     std::pair<double, bool> best(int32_t i, int64_t anc) {
         if (b.prim[(size_t) i] >= 0) return {w(anc), true}; // a Leaf box is always tested: Scene.bestCandidate's own test

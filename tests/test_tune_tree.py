@@ -138,6 +138,20 @@ def test_scenes_that_are_left_alone(orc):
         rt.check(rt.lib.rt_scene_tune_rays(None, None, 0, None))
 
 
+def test_a_probe_that_misses_the_scene_leaves_a_sane_tree():
+    """No probe ray hits anything: the counts run out at the root and every box below is priced by area -- the result must still be
+    a hierarchy (the area model thins a little), not a flat list of leaves under the root."""
+    objs, cam, w, h = rt.sample_images.config3_final()
+    s = rt.Scene.make(objs)
+    rays = np.zeros((1000, 6)); rays[:, 1] = 100.0; rays[:, 4] = 1.0
+    info = s.tune_rays(rays)
+    skip, prim, boxes = s.walk_tree()
+    check_nary(skip, prim, boxes)
+    assert info["tuned"] == 1 and skip[0] == len(skip)  # the root is tested: nothing of the probe gets past it
+    assert 0.8 * info["nodes_before"] < info["nodes_after"] < info["nodes_before"] and s.info()["walk_tree_depth"] >= 6
+    assert info["box_tests_before"] == 1.0
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_any_rays_give_a_valid_tree(seed):
     """Whatever the probe looks like -- few rays, rays that miss everything, axis-parallel and zero directions, NaNs -- the result is a
