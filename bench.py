@@ -201,7 +201,8 @@ def main():
     scene = rt.Scene.make(objs)
     # Scene preparation, once per scene and camera, outside the timed steps like Scene.make itself: the walk tree rebuilt from the
     # rays of a 16-row probe render (rt_scene_tune).  Every rank probes the same rows of the whole frame, so all walk the same tree.
-    tune = None if args.no_tune else scene.tune(w, h, cam, seed=args.seed, device=local_rank)
+    # The probe has a seed of its own: the timed frames' rays are not the rays the tree was tuned on.
+    tune = None if args.no_tune else scene.tune(w, h, cam, seed=args.seed ^ 0x5EED, device=local_rank)
     rows, cols = 2 * h + 1, 2 * w + 1
     first, stride, n = rtd.shard_rows(rows, rank, world)
     n_pad = (rows + world - 1) // world

@@ -77,6 +77,29 @@ int main(void) {
     rt_scene_info info;
     CHECK(rt_scene_get_info(scene, &info) == RT_OK);
     CHECK(info.n_bounded == 1 && info.n_unbounded == 2 && info.n_nodes == 1 && info.lds_resident == 1);
+    {   /* rt_scene_tune_rays: the host half of tuning (no GPU involved); one bounded sphere walks the reference's tree: left alone */
+        const double probe[12] = {0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.5, 0.5, -2.0, 0.0, 0.0, 1.0};
+        rt_tune_info ti;
+        memset(&ti, 0, sizeof(ti));
+        ti.struct_size = (uint32_t) sizeof(ti);
+        CHECK(rt_scene_tune_rays(scene, probe, 2, &ti) == RT_OK && ti.tuned == 0 && ti.struct_size == sizeof(ti) && ti.nodes_after == 1);
+        ti.struct_size = 0;
+        CHECK(rt_scene_tune_rays(scene, probe, 2, &ti) == RT_ERR_INVALID_ARGUMENT);
+        /* five spheres in a row: tuned, and the tree stays a tree over the same five leaves */
+        rt_hittable row[5];
+        for (int i = 0; i < 5; ++i) { row[i] = h[0]; row[i].point[0] = 3.0 * i; }
+        rt_scene *five = NULL;
+        CHECK(rt_scene_create(row, 5, NULL, 0, &five) == RT_OK);
+        ti.struct_size = (uint32_t) sizeof(ti);
+        CHECK(rt_scene_tune_rays(five, probe, 2, &ti) == RT_OK && ti.tuned == 1 && ti.probe_rays == 2 && ti.nodes_before == 9);
+        CHECK(rt_scene_get_info(five, &info) == RT_OK && info.walk_tree == RT_WALK_TREE_TUNED && info.walk_tree_nodes == ti.nodes_after && info.n_nodes == 9);
+        int32_t prim[9], leaves = 0;
+        CHECK(rt_scene_get_walk_tree(five, NULL, prim, NULL) == RT_OK);
+        for (int i = 0; i < info.walk_tree_nodes; ++i) leaves += prim[i] >= 0;
+        CHECK(leaves == 5);
+        rt_scene_destroy(five);
+        CHECK(rt_scene_get_info(scene, &info) == RT_OK);
+    }
     h[0].style = 99;
     rt_scene *bad = NULL;
     CHECK(rt_scene_create(h, 3, NULL, 0, &bad) == RT_ERR_INVALID_ARGUMENT && strstr(rt_last_error(), "bad style") != NULL);
@@ -115,6 +138,12 @@ int main(void) {
         CHECK(rt_render_frame(scene, &cam, 3, 3, 42, devices, 3, RT_RENDER_COUNTERS, RT_GATHER_PEER, &opt, accum2, rgb2, st3) == RT_OK);
         CHECK(memcmp(accum, accum2, sizeof(accum)) == 0 && memcmp(rgb, rgb2, sizeof(rgb)) == 0);
         CHECK(st3[0].rays + st3[1].rays + st3[2].rays == st.rays && st3[0].pixels == 21 && st3[2].pixels == 14);
+        /* rt_scene_tune from C: a probe render on the GPU; this scene (one bounded sphere) has nothing to tune */
+        rt_tune_info ti;
+        memset(&ti, 0, sizeof(ti));
+        ti.struct_size = (uint32_t) sizeof(ti);
+        CHECK(rt_scene_tune(scene, &cam, 3, 3, 42, 0, &ti) == RT_OK && ti.tuned == 0);
+        CHECK(rt_scene_tune(scene, &cam, 0, 3, 42, 0, &ti) == RT_ERR_INVALID_ARGUMENT);
         printf("abi_smoke: host checks ok, rendered 7x7 px: %llu samples, %llu rays\n", (unsigned long long) st.samples, (unsigned long long) st.rays);
     }
     rt_scene_destroy(scene);

@@ -2,8 +2,9 @@
 the pytest suite runs a 40-scene slice of the same idea).  Scenes: 3-60 bounded spheres of every style, overlapping and nested, now and
 then exact duplicates (equal t^2: the tie rule), negative radii, unbounded spheres and planes, cameras anywhere, bounce depths from 0.
 Every sixth sphere or so carries a parameterised texture (checkered UV ramps, an image).  Each scene is rendered with the surface-area
-walk tree and with the reference's own tree, by the counting kernel variant (compiled node loop) and by the plain one (hand-written
-node loop, the one the bench times); all must equal the oracle bit for bit."""
+walk tree, with the reference's own tree and with the tree tuned to the scene's camera (rt_scene_tune: probe render, ray-count build,
+thinning), by the counting kernel variant (compiled node loop) and by the plain one (hand-written node loop, the one the bench
+times); all must equal the oracle bit for bit."""
 import dataclasses
 import os
 import sys
@@ -67,12 +68,14 @@ def main():
     for i in range(first, first + n):
         objs, cam, w, h = scene(i)
         acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=i, threads=8)
-        for tree in ("sah", "reference"):
-            rt.set_walk_tree(tree)
+        for tree in ("sah", "reference", "tuned"):
+            rt.set_walk_tree("reference" if tree == "reference" else "sah")
             try:
                 s = rt.Scene.make(objs)
             finally:
                 rt.set_walk_tree("sah")
+            if tree == "tuned":
+                s.tune(w, h, cam, seed=i)
             for passes in ((0, 2) if i % 5 == 0 else (0,)):
                 rt.set_passes(passes)
                 try:
@@ -90,7 +93,7 @@ def main():
         rays += st["rays"]
         if (i - first) % 100 == 99:
             print(f"{i - first + 1} scenes ok, {rays} rays", flush=True)
-    print(f"fuzz campaign: {n} scenes from seed {first}, {rays} rays, both walk trees: all equal to the oracle", flush=True)
+    print(f"fuzz campaign: {n} scenes from seed {first}, {rays} rays, three walk trees (surface-area, reference, tuned): all equal to the oracle", flush=True)
 
 
 if __name__ == "__main__":
