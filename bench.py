@@ -253,6 +253,24 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
+    # the same frame over the surface-area tree as built (no rt_scene_tune), timed the same way: both numbers from one run
+    untuned = None
+    if world == 1 and tune is not None and tune["tuned"]:
+        plain = rt.Scene.make(objs)
+        st_plain = rtd.render_shard_device(plain, cam, w, h, args.seed, local_rank, first, stride, n, local, stream=stream.cuda_stream,
+                                           counters=True, want_stats=True)
+        rtd.render_shard_device(plain, cam, w, h, args.seed, local_rank, first, stride, n, local, stream=stream.cuda_stream)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            rtd.render_shard_device(plain, cam, w, h, args.seed, local_rank, first, stride, n, local, stream=stream.cuda_stream)
+            rtd.gather_frame(local, rows, cols, rank, world)
+        fence()
+        ms_plain = (time.perf_counter() - t1) * 1e3 / args.steps
+        untuned = {"ms_per_step": round(ms_plain, 3), "value": round(st_plain["rays"] / (ms_plain * 1e-3) / 1e6, 3),
+                   "aabb_tests": int(st_plain["aabb_tests"]), "note": "the same frame without rt_scene_tune (surface-area walk tree as built)"}
+        del plain
+
     tot = torch.tensor([dt, float(st["rays"]), float(st["aabb_tests"]), float(st["prim_tests"]), float(st["reflections"]),
                         float(st["samples"]), float(st["pixels_early"]), k_ms / max(1, args.steps), float(st_ref["aabb_tests"])],
                        dtype=torch.float64, device=dev)
@@ -306,7 +324,7 @@ def main():
                        "walk_tree": ("surface-area build over the reference's leaf boxes (same hits; DESIGN.md 'Walk tree')",
                                      "BoundingBoxTree.make's own",
                                      "rebuilt from the rays of a probe render and thinned (rt_scene_tune; same hits; DESIGN.md 'Walk tree')")[info["walk_tree"]],
-                       "tune": tune, "sharding": f"rows interleaved over {world} rank(s), one gather"},
+                       "tune": tune, "without_tune": untuned, "sharding": f"rows interleaved over {world} rank(s), one gather"},
             "job": {**job, "pixels": rows * cols, "wall_s_per_frame": round(ms_per_step / 1e3, 4),
                     "ray_sphere_tests_per_s": round(job["prim_tests"] / (ms_per_step * 1e-3), 1),
                     "aabb_tests_per_s": round(job["aabb_tests"] / (ms_per_step * 1e-3), 1),
