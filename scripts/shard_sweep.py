@@ -7,11 +7,12 @@ from ray_tracing_fsharp_amd import distributed as rtd
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 objs, cam, w, h = rt.sample_images.config3_final()
 scene = rt.Scene.make(objs)
+scene.tune(w, h, cam, seed=7)
 rows, cols = 2 * h + 1, 2 * w + 1
 first, stride, n = rtd.shard_rows(rows, 0, world)
 local = torch.zeros((n, cols, 4), dtype=torch.int32, device="cuda:0")
 for chunk in (0, 4, 8, 16):
-    for refill in (0, 6, 20):
+    for refill in (0, 8, 12, 24):
         rt.set_launch_config(0, chunk); rt.set_schedule(0, refill)
         ts = []
         for _ in range(4):
