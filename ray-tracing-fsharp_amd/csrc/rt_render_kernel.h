@@ -155,6 +155,7 @@ struct Sched {
     Rng rng;
     uint32_t colour, slotOff;
     int bounces;
+    uint32_t pend; // queue of pending leaf tests (node_loop_lds); always 0 outside a walk and in the variants that do not queue
     // set by the stages for the caller's bookkeeping: this lane's path ended during the current turn, with this colour
     bool ended;
     uint32_t result;
@@ -165,7 +166,7 @@ struct Sched {
         o = mk(0, 0, 0); d = mk(0, 0, 0);
         walk_begin(w, sc.first); w.off = end; // idle lanes are parked at `end`
         rng.x = rng.y = rng.z = rng.w = 0;
-        colour = 0; slotOff = 0; bounces = 0;
+        colour = 0; slotOff = 0; bounces = 0; pend = 0u;
         ended = false; result = 0;
     }
 
@@ -269,9 +270,21 @@ struct Sched {
         const int nBusy = __popcll(__builtin_amdgcn_ballot_w64(st != L_IDLE));
         WalkCtx c = walk_ctx(d, w); // cheap to re-derive; keeps 9 doubles out of the parked state
         const int stop = (nBusy - p.yield_lanes) > 0 ? (nBusy - p.yield_lanes) : 0; // active <= stop  <=>  waiting >= yield
+        if constexpr (LDS && !COUNT) {
+            // the timed variant: the hand-written loop with its queue of pending leaf tests (rt_device.h); a lane is finished when its
+            // walk is exhausted AND its queue is empty
+            for (;;) {
+                w.off = node_loop_lds(w.off, pend, end, stop, o, c);
+                if (pend != 0u) leaf_test_object<LDS>(sc, o, d, c, w, pend_pop(pend));
+                const bool fin = (st == L_WALK) && (w.off >= end) && pend == 0u;
+                if (fin) st = L_DONE;
+                const int nWalk = __popcll(__builtin_amdgcn_ballot_w64(st == L_WALK));
+                const int nDone = __popcll(__builtin_amdgcn_ballot_w64(st == L_DONE));
+                if (nWalk == 0 || nDone >= p.yield_lanes) break;
+            }
+            return;
+        }
         for (;;) {
-            if constexpr (LDS && !COUNT) w.off = node_loop_lds(w.off, end, stop, o, c);
-            else
             for (;;) {
                 const bool act = w.off < end;
                 const int nAct = __popcll(__builtin_amdgcn_ballot_w64(act));
@@ -533,7 +546,9 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
 
 // Stages the LDS part of the scene image (node, geo, meta) into the workgroup's LDS, 16 B per lane per trip, coalesced, and makes
 // the node links absolute LDS addresses: a walk position then IS the record's address (no add per visit).  Returns the bytes used.
-template <int BLOCK>
+// QUEUE (the timed variant, node_loop_lds): a Leaf's on_hit link becomes its on_miss link (the walk goes on), the third link word its
+// queue entry RTD_PEND_MARK | object, the fourth the shift 16; a Branch gets 0 and 0 there.
+template <int BLOCK, bool QUEUE>
 RTD_INLINE uint32_t stage_scene(const RenderParams &p, unsigned char *smem) {
     const uint32_t sceneBytes = p.off.lds_total;
     const d2 *src = (const d2 *) p.scene_image;
@@ -543,10 +558,16 @@ RTD_INLINE uint32_t stage_scene(const RenderParams &p, unsigned char *smem) {
     RTD_AS3 unsigned char *nodes = (RTD_AS3 unsigned char *) smem + p.off.node;
     const int first = (int) (uint32_t) (uintptr_t) nodes;
     for (int i = threadIdx.x; i < p.off.n_nodes; i += BLOCK) {
-        RTD_AS3 i2 *lk = (RTD_AS3 i2 *) (nodes + i * RTD_NODE_BYTES + 96);
-        i2 v = *lk;
+        RTD_AS3 i4 *lk = (RTD_AS3 i4 *) (nodes + i * RTD_NODE_BYTES + 96);
+        i4 v = *lk; // on_hit, on_miss, prim, 0
         v.x += first; // a Leaf's RTD_LEAF flag (bit 30) is above every LDS address and survives the add
         v.y += first;
+        if (QUEUE) {
+            const bool leaf = v.z >= 0;
+            if (leaf) v.x = v.y;
+            v.w = leaf ? 16 : 0;
+            v.z = leaf ? (int) (RTD_PEND_MARK | (uint32_t) v.z) : 0;
+        }
         *lk = v;
     }
     __syncthreads();
@@ -567,7 +588,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    const uint32_t sceneBytes = LDS ? stage_scene<BLOCK>(p, smem) : 0u;
+    const uint32_t sceneBytes = LDS ? stage_scene<BLOCK, !COUNT>(p, smem) : 0u;
     const SceneView<LDS> sc = make_view<LDS>(p, smem);
     const uint32_t P = (uint32_t) p.chunk;
     RTD_AS3 uint32_t *wv = (RTD_AS3 uint32_t *) (smem + sceneBytes) + (size_t) wave * (MODE == 1 ? RTD_WAVE_WORDS_A(P) : RTD_WAVE_WORDS(P));

@@ -1124,7 +1124,7 @@ __global__ void k_hit_object(const RenderParams p, int n, const double *rays, in
 // (node_loop_lds), leaf tests between its runs, the unbounded objects last.  One ray per lane, 1024 rays per workgroup.
 __global__ void __launch_bounds__(1024) k_hit_object_lds(const RenderParams p, int n, const double *rays, int32_t *hit, double *strike) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    (void) stage_scene<1024>(p, smem);
+    (void) stage_scene<1024, true>(p, smem);
     const SceneView<true> sc = make_view<true>(p, smem);
     const int i = blockIdx.x * 1024 + threadIdx.x;
     const bool valid = i < n;
@@ -1134,10 +1134,11 @@ __global__ void __launch_bounds__(1024) k_hit_object_lds(const RenderParams p, i
     walk_begin(w, sc.first);
     if (!valid) w.off = sc.end;
     WalkCtx c = walk_ctx(d, w);
+    uint32_t pend = 0u;
     for (;;) {
-        w.off = node_loop_lds(w.off, sc.end, 0, o, c); // until no lane of the wave is walking
-        if (__builtin_amdgcn_ballot_w64((w.off & RTD_LEAF) != 0) == 0ull) break;
-        if (w.off & RTD_LEAF) leaf_test<true>(sc, o, d, c, w);
+        w.off = node_loop_lds(w.off, pend, sc.end, 0, o, c); // until no lane of the wave can step: walks exhausted or queues full
+        if (__builtin_amdgcn_ballot_w64(pend != 0u) == 0ull) break;
+        if (pend != 0u) leaf_test_object<true>(sc, o, d, c, w, pend_pop(pend));
     }
     Counters cnt; cnt.rays = cnt.aabb = cnt.prim = cnt.refl = 0;
     unbounded_tests<true, false>(sc, o, d, w, cnt);
