@@ -1,5 +1,6 @@
 """rt_scene_tune on the GPU: the probe render, the rebuilt (n-ary, thinned) walk tree, and -- the point -- that no pixel and no
-counter other than the box tests changes.  The whole suite also runs with every scene tuned (RTFS_TUNE=1, conftest.py)."""
+counter other than the box tests changes.  (Scenes are made with walk_tree="sah" explicitly: a scene that walks the reference's own tree,
+the process default under the RTFS_TREE=reference knob, is left alone by the tune.)  The whole suite also runs with every scene tuned (RTFS_TUNE=1, conftest.py)."""
 import dataclasses
 import os
 
@@ -21,9 +22,9 @@ def _same_but_for_box_tests(a, b):
 
 def test_tuned_final_scene_thumbnail_equals_untuned_and_oracle(rt, orc):
     objs, cam, w, h = scenes.small_final(spp=60, pixels=40)
-    plain = rt.Scene.make(objs)
+    plain = rt.Scene.make(objs, walk_tree="sah")
     base = plain.render_rows(w, h, cam, seed=5, counters=True)
-    s = rt.Scene.make(objs)
+    s = rt.Scene.make(objs, walk_tree="sah")
     first = s.render_rows(w, h, cam, seed=5, counters=True)  # a device copy of the image exists before the tune replaces it
     info = s.tune(w, h, cam, seed=5)
     assert info["tuned"] == 1 and info["probe_rows"] == 16 and info["probe_rays"] >= 1000 and info["probe_ms"] > 0
@@ -41,12 +42,12 @@ def test_tuned_final_scene_thumbnail_equals_untuned_and_oracle(rt, orc):
     acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=5, threads=8)
     assert np.array_equal(tuned.accum, acc) and np.array_equal(tuned.rgb, rgb) and tuned.stats["rays"] == st["rays"]
     # a fresh scene tuned before its first render, and the same probe, give the same tree
-    t = rt.Scene.make(objs)
+    t = rt.Scene.make(objs, walk_tree="sah")
     t.tune(w, h, cam, seed=5)
     assert all(np.array_equal(a, b) for a, b in zip(t.walk_tree(), s.walk_tree()))
     assert np.array_equal(t.render_rows(w, h, cam, seed=5).accum, base.accum)
     # another camera / seed for the probe: another tree, the same pixels
-    u = rt.Scene.make(objs)
+    u = rt.Scene.make(objs, walk_tree="sah")
     u.tune(w // 2, h // 2, cam, seed=99)
     assert np.array_equal(u.render_rows(w, h, cam, seed=5).accum, base.accum)
 
@@ -56,7 +57,7 @@ def test_catalogue_scenes_tuned(rt, orc, name):
     objs, cam, w, h = rt.sample_images.get(name)()
     cam = dataclasses.replace(cam, SamplesPerPixel=24)
     w, h = max(1, w // 20), max(1, h // 20)
-    s = rt.Scene.make(objs)
+    s = rt.Scene.make(objs, walk_tree="sah")
     base = s.render_rows(w, h, cam, seed=3, counters=True)
     s.tune(w, h, cam, seed=3)
     _same_but_for_box_tests(s.render_rows(w, h, cam, seed=3, counters=True), base)
@@ -69,7 +70,7 @@ def test_random_scenes_tuned(rt, orc, seed):
     """The fuzz scenes of test_gpu_parity (every style, negative radii, duplicates, planes, textures, cameras inside objects), tuned:
     equal to the oracle."""
     objs, cam, w, h = scenes.random_scene(3000 + seed)
-    s = rt.Scene.make(objs)
+    s = rt.Scene.make(objs, walk_tree="sah")
     info = s.tune(w, h, cam, seed=seed)
     res = s.render_rows(w, h, cam, seed=seed, counters=True)
     plain = s.render_rows(w, h, cam, seed=seed)
@@ -88,18 +89,18 @@ def test_tune_leaves_reference_tree_scenes_and_the_callers_device_alone(rt):
     assert s.tune(w, h, cam)["tuned"] == 0 and s.info()["walk_tree"] == 1
     assert all(np.array_equal(a, b) for a, b in zip(s.walk_tree(), before))
     dev = torch.cuda.current_device()
-    rt.Scene.make(objs).tune(w, h, cam)
+    rt.Scene.make(objs, walk_tree="sah").tune(w, h, cam)
     assert torch.cuda.current_device() == dev
     with pytest.raises(Exception):
-        rt.Scene.make(objs).tune(0, h, cam)
+        rt.Scene.make(objs, walk_tree="sah").tune(0, h, cam)
     with pytest.raises(Exception):
-        rt.Scene.make(objs).tune(w, h, cam, device=99)
+        rt.Scene.make(objs, walk_tree="sah").tune(w, h, cam, device=99)
 
 
 def test_render_frame_over_a_tuned_scene(rt):
     """rt_render_frame (one process, several entries of the device list) after a tune: every device copy holds the new image."""
     objs, cam, w, h = scenes.small_final(spp=30, pixels=20)
-    s = rt.Scene.make(objs)
+    s = rt.Scene.make(objs, walk_tree="sah")
     want = s.render_rows(w, h, cam, seed=8)
     got0 = s.render_frame(w, h, cam, seed=8, devices=[0, 0])
     s.tune(w, h, cam, seed=8)
@@ -111,8 +112,8 @@ def test_full_size_config3_tuned(rt):
     """BASELINE config 3 whole, tuned as bench.py does: the frame and every counter but the box tests equal the untuned run's (which
     test_full_size_config3_equals_the_oracle holds to the oracle), at about 17 box tests per ray instead of 23.8."""
     objs, cam, w, h = rt.sample_images.config3_final()
-    a = rt.Scene.make(objs).render_rows(w, h, cam, seed=2024, counters=True)
-    s = rt.Scene.make(objs)
+    a = rt.Scene.make(objs, walk_tree="sah").render_rows(w, h, cam, seed=2024, counters=True)
+    s = rt.Scene.make(objs, walk_tree="sah")
     info = s.tune(w, h, cam, seed=2024)
     b = s.render_rows(w, h, cam, seed=2024, counters=True)
     c = s.render_rows(w, h, cam, seed=2024)
