@@ -152,7 +152,8 @@ static LaunchPlan plan_launch(const rth::HostScene &h, const Settings &s) {
     p.block = s.block ? s.block : 1024;
     p.chunk = s.chunk ? s.chunk : 16;
     p.park = s.park < 0 ? 0 : (s.park ? s.park : RTD_PARK_DEFAULT);
-    auto fits = [&](int block, int chunk) { return lds_need(h, true, block, chunk) <= RT_LDS_BYTES; };
+    // (an LDS-resident scene has far fewer than the 16384 objects the node loop's 14-bit queue entries can name: 48 B each of 160 KiB)
+    auto fits = [&](int block, int chunk) { return h.nBounded + h.nUnbounded < 16384u && lds_need(h, true, block, chunk) <= RT_LDS_BYTES; };
     if (fits(p.block, p.chunk)) { p.lds = true; return p; }
     if (p.block > 256 && fits(256, p.chunk)) { p.block = 256; p.lds = true; return p; }
     return p; // global-memory variant: LDS holds only the waves' scratch, which always fits
