@@ -14,7 +14,9 @@ import ray_tracing_fsharp_amd as rt  # noqa: E402
 
 objs, cam, _, _ = rt.sample_images.config3_final(seed=2024, spp=1000, depth=50)
 w, h = 3840, 2160
-res = rt.Scene.make(objs).render_rows(w, h, cam, seed=2024)
+scene = rt.Scene.make(objs)
+print("tune:", scene.tune(w, h, cam, seed=2024 ^ 0x5EED), flush=True)  # the bench's configuration: tuned walk tree, timed kernel variant
+res = scene.render_rows(w, h, cam, seed=2024)
 print(f"HIP: {res.stats['samples']} samples, kernel {res.stats['kernel_ms']:.1f} ms", flush=True)
 t0 = time.time()
 rows = 2 * h + 1

@@ -15,8 +15,10 @@ import ray_tracing_fsharp_amd as rt  # noqa: E402
 earth = np.load(os.path.join(ROOT, "tests", "golden", "earthmap_rgb.npz"))["rgb"]
 objs, cam, w, h = rt.sample_images.config5_mixed(earth)
 t0 = time.time()
-res = rt.Scene.make(objs).render_rows(w, h, cam, seed=5, counters=True)
-plain = rt.Scene.make(objs).render_rows(w, h, cam, seed=5)
+scene = rt.Scene.make(objs)
+print("tune:", scene.tune(w, h, cam, seed=5 ^ 0x5EED), flush=True)  # the bench's configuration: tuned walk tree
+res = scene.render_rows(w, h, cam, seed=5, counters=True)
+plain = scene.render_rows(w, h, cam, seed=5)
 print(f"HIP: {res.stats['rays']} rays, kernel {plain.stats['kernel_ms']:.1f} ms (counting variant {res.stats['kernel_ms']:.1f} ms)", flush=True)
 t0 = time.time()
 acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=5, threads=int(sys.argv[1]) if len(sys.argv) > 1 else 16)
