@@ -170,7 +170,7 @@ int rt_scene_get_walk_tree(const rt_scene *scene, int32_t *skip, int32_t *prim, 
 
 /* ---- Tuning the walk tree to a camera (no counterpart in the reference: BoundingBoxTree.make knows no rays) ----------
  * Renders a PROBE with the scene as it stands -- 16 image rows spread over the frame, through the counting kernel, which logs a
- * thinned-out sample of the rays it traces (a few ten thousand: origin and direction) -- and rebuilds the tree the device walks
+ * thinned-out sample of the rays it traces (8192 are used: origin and direction) -- and rebuilds the tree the device walks
  * from them: split costs are the number of probe rays that hit a candidate box (not its area), and Branch boxes that nearly
  * every arriving ray hits are not tested at all (their children take their place; csrc/rt_scene.h "thinning").  Every pixel
  * stays the same bit for bit, as under rt_set_walk_tree and for the same reason; what changes is aabb_tests (final scene:
@@ -180,7 +180,9 @@ int rt_scene_get_walk_tree(const rt_scene *scene, int32_t *skip, int32_t *prim, 
  * A scene that walks the reference's own tree (RT_WALK_TREE_REFERENCE, or fewer than 3 bounded spheres, or non-finite boxes)
  * is left alone: tuned = 0.  Must not run concurrently with renders of the same scene: it replaces the device images (after
  * waiting for the devices that hold one).  Typical use: once after rt_scene_create, with the camera and image size of the
- * frames to come; the cost is a few milliseconds of GPU time plus the host build (final scene: 8 + 90 ms). */
+ * frames to come.  Cost on the final scene: ~8 ms of GPU time for the probe + ~20 ms of host time for the build, against ~22 ms
+ * saved per 2401x1601x500spp frame (0.4 s per 7681x4321x1000spp frame): it pays from the second frame of a scene on, or on the
+ * first if that one takes more than about a quarter of a second. */
 typedef struct rt_tune_info {
     uint32_t struct_size;      /* sizeof(rt_tune_info) as the caller compiled it */
     int32_t  tuned;            /* 1: the walk tree was replaced */
@@ -192,7 +194,7 @@ typedef struct rt_tune_info {
 } rt_tune_info;
 int rt_scene_tune(rt_scene *scene, const rt_camera *camera, int32_t max_width_coord, int32_t max_height_coord, uint64_t seed,
                   int32_t device, rt_tune_info *info /* may be NULL */);
-/* The host half alone, with the caller's own probe: rays[n_rays][6] = origin xyz, direction xyz (at most 32768 of them are used,
+/* The host half alone, with the caller's own probe: rays[n_rays][6] = origin xyz, direction xyz (at most 8192 of them are used,
  * evenly spaced).  Touches a GPU only to replace device copies of the image that already exist.  probe_rows and probe_ms stay 0. */
 int rt_scene_tune_rays(rt_scene *scene, const double *rays, size_t n_rays, rt_tune_info *info /* may be NULL */);
 

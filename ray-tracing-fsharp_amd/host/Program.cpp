@@ -58,9 +58,10 @@ int main(int argc, char **argv) {
                       << " walkDepth=" << si.walk_tree_depth << "\n";
             return 0;
         }
-        // frames of more than ~1e8 samples repay the tenth of a second rt_scene_tune takes (same pixels, fewer box tests per ray)
+        // one frame per scene here: rt_scene_tune (~30 ms for a probe and a tree build; same pixels, ~12 % off the frame time) repays
+        // itself on frames of more than about a quarter of a second, i.e. from ~3e9 pixel-samples on
         const double samples = (double) (2 * def.maxWidthCoord + 1) * (double) (2 * def.maxHeightCoord + 1) * (double) def.camera.SamplesPerPixel;
-        if (samples >= 1e8) {
+        if (samples >= 3e9) {
             const rt_tune_info ti = scene->tune(def.maxWidthCoord, def.maxHeightCoord, def.camera, seed, device);
             if (ti.tuned) std::fprintf(stderr, "walk tree tuned: %.1f -> %.1f box tests per probe ray, %d -> %d nodes, %.0f ms\n", ti.box_tests_before,
                                        ti.box_tests_after, ti.nodes_before, ti.nodes_after, ti.probe_ms + ti.build_ms);
