@@ -363,8 +363,8 @@ int rt_dev_reflection(int32_t device, const rt_scene *scene, int32_t n, const in
 /* Scene.hitObject (Scene.fs:62-91): hit_index = index into the rt_scene_create array or -1; strike n*3; counters optional (n*2: aabb, prim). */
 int rt_dev_hit_object(int32_t device, const rt_scene *scene, int32_t n, const double *rays,
                       int32_t *hit_index, double *strike, uint32_t *counters);
-/* The same through the render kernel's timed route: scene staged into LDS, the hand-written node loop, leaf tests between its
- * runs, the unbounded objects last (RT_ERR_UNSUPPORTED when the scene does not fit the LDS). */
+/* The same through the render kernel's timed route: scene staged into LDS, the hand-written node loop with its per-lane queue of
+ * pending leaf tests, leaf passes between its runs, the unbounded objects last (RT_ERR_UNSUPPORTED when the scene does not fit the LDS). */
 int rt_dev_hit_object_lds(int32_t device, const rt_scene *scene, int32_t n, const double *rays, int32_t *hit_index, double *strike);
 /* Scene.traceRay (Scene.fs:93-114) from White for given rays and RNG states. colour_out n*3. */
 int rt_dev_trace_ray(int32_t device, const rt_scene *scene, int32_t bounce_depth, int32_t n, const double *rays,
