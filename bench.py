@@ -154,7 +154,9 @@ def main():
                     help="nccl (= RCCL) is the product path; gloo stages the gather through host memory and lets several ranks share one GPU (rehearsal only)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--no-untuned-leg", action="store_true", help="skip the extra timing of the same frame without rt_scene_tune (keeps a kernel trace of this run to one configuration)")
+    ap.add_argument("--untuned-leg", action="store_true", help="also time the same frame WITHOUT rt_scene_tune in this run (config.without_tune); off by default so that a "
+                                                               "kernel trace of the default run holds one configuration of the timed kernel")
+    ap.add_argument("--no-untuned-leg", action="store_true", help=argparse.SUPPRESS)  # the default now; accepted for older command lines
     ap.add_argument("--no-tune", action="store_true", help="walk the surface-area tree as built, without rt_scene_tune's probe")
     args = ap.parse_args()
 
@@ -256,7 +258,7 @@ def main():
 
     # the same frame over the surface-area tree as built (no rt_scene_tune), timed the same way: both numbers from one run
     untuned = None
-    if world == 1 and tune is not None and tune["tuned"] and not args.no_untuned_leg:
+    if world == 1 and tune is not None and tune["tuned"] and args.untuned_leg:
         plain = rt.Scene.make(objs)
         st_plain = rtd.render_shard_device(plain, cam, w, h, args.seed, local_rank, first, stride, n, local, stream=stream.cuda_stream,
                                            counters=True, want_stats=True)
