@@ -202,6 +202,45 @@ def test_hit_object_through_the_hand_written_node_loop(rt, orc):
         assert 0.05 < np.mean(h2 >= 0) <= 1.0
 
 
+def test_leaf_queue_of_the_node_loop_under_pressure(rt, orc):
+    """The timed variant's node loop queues hit Leaves (two 16-bit entries per lane) and stops a lane only when its queue is full.
+    Rays that run through dozens of overlapping Leaf boxes -- a skewer of nested and overlapping spheres, exact duplicates among them
+    (the tie rule decides between equal t^2) -- fill the queues over and over; rays from inside, from far away, and ones that miss."""
+    P, S, H, Px, Tex = scenes.P, scenes.S, scenes.H, scenes.Px, scenes.Tex
+    rng = np.random.default_rng(31)
+    objs = []
+    for i in range(70):  # along the z axis: nested shells and overlapping neighbours
+        c = P(0.02 * float(rng.normal()), 0.02 * float(rng.normal()), 0.25 * i)
+        r = float(rng.uniform(0.2, 3.0)) * (-1.0 if i % 11 == 0 else 1.0)
+        objs.append(H.Sphere(rt.Sphere.make(S.LambertReflection(0.5, Tex(Px(9, 9, 9))), c, r)))
+        if i % 6 == 0:
+            objs.append(H.Sphere(rt.Sphere.make(S.PureReflection(0.5, Tex(Px(1, 2, 3))), c, r)))  # the same sphere twice
+    for i in range(60):  # and a cloud around it
+        objs.append(H.Sphere(rt.Sphere.make(S.Glass(0.9, Tex(Px(7, 7, 7)), 1.5), P(float(rng.uniform(-6, 6)), float(rng.uniform(-6, 6)), float(rng.uniform(0, 18))), float(rng.uniform(0.1, 1.0)))))
+    objs.append(H.UnboundedSphere(rt.Sphere.make(S.LightSource(Tex(Px(200, 200, 255))), P(0.0, 0.0, 0.0), 500.0)))
+    n = 60000
+    rays = scenes.random_rays(n, 5, origin_scale=4.0)
+    k = n // 4
+    rays[:k, :3] = np.stack([0.05 * rng.normal(size=k), 0.05 * rng.normal(size=k), rng.uniform(-30, -3, k)], 1)  # down the skewer
+    d = np.stack([0.01 * rng.normal(size=k), 0.01 * rng.normal(size=k), np.ones(k)], 1)
+    rays[:k, 3:] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[k:2 * k, :3] = np.stack([0.3 * rng.normal(size=k), 0.3 * rng.normal(size=k), rng.uniform(0, 17, k)], 1)  # from inside the shells
+    for tree in ("sah", "reference"):
+        s, o = rt.Scene.make(objs, walk_tree=tree), orc.OracleScene(objs)
+        assert s.info()["lds_resident"] == 1
+        if tree == "sah":
+            s.tune_rays(rays[::7])  # a thinned tree: more Leaves per Branch, longer runs of consecutive Leaf hits
+        h1, s1 = rt.hooks.hit_object_lds(s, rays)
+        h0, s0, c0 = rt.hooks.hit_object(s, rays)
+        h2, s2, c2 = o.hit_object(rays)
+        assert np.array_equal(h1, h2) and _same_f64(s1, s2)
+        assert np.array_equal(h0, h2) and _same_f64(s0, s2) and np.array_equal(c0[:, 1], c2[:, 1])
+        assert c2[:k, 1].mean() > 25  # the skewer rays really do meet dozens of Leaf boxes each
+    # and whole renders of the same scene (queue + lane scheduler + shading), counting variant against timed variant against oracle
+    cam = dataclasses.replace(rt.Camera.makeBasic(40, 1.0, 1.0, P(0.0, 0.0, -8.0), scenes.unit(0.0, 0.0, 1.0), scenes.V(0.0, 1.0, 0.0)), BounceDepth=12)
+    _assert_render_equal(*_render_both(rt, orc, objs, cam, 12, 12, seed=3))
+
+
 def test_reflection_every_style(rt, orc):
     objs, *_ = scenes.all_materials()
     s, o = _scene_pair(rt, orc, objs)
