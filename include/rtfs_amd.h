@@ -180,9 +180,9 @@ int rt_scene_get_walk_tree(const rt_scene *scene, int32_t *skip, int32_t *prim, 
  * A scene that walks the reference's own tree (RT_WALK_TREE_REFERENCE, or fewer than 3 bounded spheres, or non-finite boxes)
  * is left alone: tuned = 0.  Must not run concurrently with renders of the same scene: it replaces the device images (after
  * waiting for the devices that hold one).  Typical use: once after rt_scene_create, with the camera and image size of the
- * frames to come.  Cost on the final scene: ~8 ms of GPU time for the probe + ~20 ms of host time for the build, against ~22 ms
+ * frames to come.  Cost on the final scene: ~8 ms of GPU time for the probe + ~12 ms of host time for the build, against ~22 ms
  * saved per 2401x1601x500spp frame (0.4 s per 7681x4321x1000spp frame): it pays from the second frame of a scene on, or on the
- * first if that one takes more than about a quarter of a second. */
+ * first if that one takes more than about 0.15 s. */
 typedef struct rt_tune_info {
     uint32_t struct_size;      /* sizeof(rt_tune_info) as the caller compiled it */
     int32_t  tuned;            /* 1: the walk tree was replaced */

@@ -147,6 +147,7 @@ class SahBuilder {
     std::vector<uint32_t> cntP, cntS;
     static const size_t kSweepMax = 4096; // above this a node is split on 32 centroid bins per axis instead of a full sweep
     static const size_t kProbeMin = 32;   // fewer probe rays than this in a box: its subtree is split by area
+    static const size_t kSweepRays = 512; // rays a sweep looks at, at most (about)
     double centroid2(int32_t id, int axis) const { return ob[(size_t) id].mn[axis] + ob[(size_t) id].mx[axis]; }
     void sort_axis(int32_t *ids, size_t n, int axis) const {
         std::sort(ids, ids + n, [&](int32_t a, int32_t b) {
@@ -194,8 +195,11 @@ class SahBuilder {
                         for (size_t i = 2; i < n; ++i) pre[i] = merge_two(pre[i - 1], ob[(size_t) ids[i - 1]]);
                         suf[n - 1] = ob[(size_t) ids[n - 1]];
                         for (size_t i = n - 1; i-- > 1;) suf[i] = merge_two(suf[i + 1], ob[(size_t) ids[i]]);
-                        for (uint32_t r : hidx) {
-                            const ProbeRay &ray = (*rays)[r];
+                        // a sweep needs the counts to a few percent only: every step-th ray of a large set (the set itself stays whole
+                        // for the boxes below and for the thinning)
+                        const size_t step = hidx.size() / kSweepRays > 1 ? hidx.size() / kSweepRays : 1;
+                        for (size_t j = 0; j < hidx.size(); j += step) {
+                            const ProbeRay &ray = (*rays)[hidx[j]];
                             size_t lo = 1, hi = n; // first k in [1, n) with pre[k] hit, n if none
                             while (lo < hi) { const size_t mid = (lo + hi) / 2; if (probe_hits(ray, pre[mid])) hi = mid; else lo = mid + 1; }
                             cntP[lo]++;
@@ -204,11 +208,11 @@ class SahBuilder {
                             cntS[lo]++;
                         }
                         uint64_t hs = 0;
-                        for (size_t i = n - 1; i >= 1; --i) { hs += cntS[i]; suffix[i] = (double) hs; }
+                        for (size_t i = n - 1; i >= 1; --i) { hs += cntS[i]; suffix[i] = (double) (hs * step); }
                         uint64_t hp = 0;
                         for (size_t i = 1; i < n; ++i) { // left = ids[0, i), right = ids[i, n)
                             hp += cntP[i];
-                            const double cost = ((double) hp + 1.0) * subtree_weight(i) + (suffix[i] + 1.0) * subtree_weight(n - i);
+                            const double cost = ((double) (hp * step) + 1.0) * subtree_weight(i) + (suffix[i] + 1.0) * subtree_weight(n - i);
                             if (bestAxis < 0 || cost < bestCost) { bestCost = cost; bestAxis = axis; k = i; }
                         }
                     } else if (n <= kSweepMax) {

@@ -58,8 +58,8 @@ int main(int argc, char **argv) {
                       << " walkDepth=" << si.walk_tree_depth << "\n";
             return 0;
         }
-        // one frame per scene here: rt_scene_tune (~30 ms for a probe and a tree build; same pixels, ~12 % off the frame time) repays
-        // itself on frames of more than about a quarter of a second, i.e. from ~3e9 pixel-samples on
+        // one frame per scene here: rt_scene_tune (~20 ms for a probe and a tree build; same pixels, ~12 % off the frame time) repays
+        // itself on frames of more than about 0.15 s; from ~3e9 pixel-samples on it is a clear gain
         const double samples = (double) (2 * def.maxWidthCoord + 1) * (double) (2 * def.maxHeightCoord + 1) * (double) def.camera.SamplesPerPixel;
         if (samples >= 3e9) {
             const rt_tune_info ti = scene->tune(def.maxWidthCoord, def.maxHeightCoord, def.camera, seed, device);

@@ -270,8 +270,8 @@ class Scene {
     }
 
     // rt_scene_tune (no counterpart in the reference): the walk tree rebuilt from the rays of a small probe render with this camera;
-    // same pixels, about a third fewer box tests per ray, ~12 % off the frame time.  Costs ~30 ms: worth it from a scene's second frame on, or
-    // for a first frame of more than about a quarter of a second.
+    // same pixels, about a third fewer box tests per ray, ~12 % off the frame time.  Costs ~20 ms: worth it from a scene's second frame on, or
+    // for a first frame of more than about 0.15 s.
     rt_tune_info tune(int maxWidthCoord, int maxHeightCoord, const Camera &camera, uint64_t seed = 0, int device = 0) {
         rt_tune_info info{};
         info.struct_size = sizeof(info);
