@@ -347,6 +347,13 @@ int rt_dev_stream_state(int32_t device, uint64_t seed, int32_t n, const uint64_t
                         uint32_t *state_out /* n*4 */);
 /* BoundingBox.inverseDirections + hits (BoundingBox.fs:25-94). rays: n*6 (origin, unit dir); boxes: n*6 (min xyz, max xyz). */
 int rt_dev_bbox_hits(int32_t device, int32_t n, const double *rays, const double *boxes, int32_t *hit_out);
+/* The timed kernel's node loop does not run BoundingBox.hits on the boxes ABOVE the leaves: it runs a conservative
+ * single-precision filter F with hits(box) => F(box) (csrc/rt_device.h, "the node loop of the timed variant"), and the leaf pass
+ * then makes the Leaf's own BoundingBox.hits exactly -- the set of spheres tested is the reference's (Scene.fs:39-60).  This hook
+ * runs both on n (ray, box) pairs: out[i] bit 0 = the exact test, bit 1 = F in the loop's own instruction forms, bit 2 = F as
+ * compiled C++.  Boxes are rounded outward to single precision as the scene image does; bmax (>= 0) enlarges the margin's scale
+ * beyond the batch's largest |coordinate| (the scene image uses the largest |coordinate| of its tree). */
+int rt_dev_bbox_filter(int32_t device, int32_t n, const double *rays, const double *boxes, double bmax, int32_t *out);
 /* Sphere.firstIntersection (Sphere.fs:349-386). spheres: n*4 (centre xyz, radius). t_out = NaN when ValueNone. */
 int rt_dev_sphere_first_intersection(int32_t device, int32_t n, const double *rays, const double *spheres, double *t_out);
 /* InfinitePlane.intersection (InfinitePlane.fs:125-136). planes: n*6 (point, unit normal). */

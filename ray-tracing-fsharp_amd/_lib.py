@@ -9,7 +9,8 @@ import os
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtfs_amd.so")
+# RTFS_LIB: another build of the same library (kernel A/B experiments, scripts/ab.sh); the default is the in-tree product build
+LIB_PATH = os.environ.get("RTFS_LIB") or os.path.join(_HERE, "librtfs_amd.so")
 
 
 class RtError(RuntimeError):
@@ -91,6 +92,7 @@ SIGNATURES = {
     "rt_dev_float_producer": (C.c_int, [C.c_int32, _u32p, C.c_int32, _dp]),
     "rt_dev_stream_state": (C.c_int, [C.c_int32, C.c_uint64, C.c_int32, _u64p, _u32p, _u32p]),
     "rt_dev_bbox_hits": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _i32p]),
+    "rt_dev_bbox_filter": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, C.c_double, _i32p]),
     "rt_dev_sphere_first_intersection": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "rt_dev_plane_intersection": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "rt_dev_pixel_combine": (C.c_int, [C.c_int32, C.c_int32, _u8p, _u8p, _u8p]),

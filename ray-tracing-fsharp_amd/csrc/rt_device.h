@@ -211,15 +211,22 @@ RTD_INLINE double pow5(double x) {
 //                          one position and nothing else.  prim = object index of a Leaf, -1 for a Branch.  The LDS copy
 //                          holds ABSOLUTE LDS addresses in both links (patched when the image is staged), so a walk
 //                          position is used as an address as it is.
-//   geo  [n_obj][3]  d2    sphere {cx,cy}{cz,r^2}{albedo,spare} | plane {px,py}{pz,nx}{ny,nz}   48 B/object
+//   geo  [n_obj][3]  d2    sphere {cx,cy}{cz,r^2}{albedo,radius} | plane {px,py}{pz,nx}{ny,nz}   48 B/object
 //   meta [n_obj]     i2    {kind|style<<2|flipped<<5, rgb|(texture+1)<<24}                   8 B/object
-//   mat  [n_obj][4]  double sphere {radius, fuzz|ior, prob, 1/ior} (Dielectric) | {radius, ior, 1/ior, schlickOutside} (Glass, whose
-//                          schlickInside sits in the sphere record's spare double): per-material values of Sphere.fs:117,283-289;
-//                          plane {albedo, fuzz, 0, 0}                                         32 B/object, global memory
+//   node32 [n_nodes] 64 B  {lo,hi,hi,lo}_x {lo,hi,hi,lo}_y {lo,hi,hi,lo}_z : FLOAT; on_hit, on_miss, prim, pad : int32
+//                          The same tree with every box rounded OUTWARD to single precision (lo down, hi up): the records of the
+//                          timed kernel variant's node loop, which runs a conservative single-precision filter instead of the exact
+//                          test (node_loop_lds32) and leaves the exact BoundingBox.hits to the leaf pass.  Links as in `node`, in
+//                          units of 64 B.
+//   mat  [n_obj][4]  double sphere {-, fuzz|ior, prob, 1/ior} (Dielectric) | {schlickInside, ior, 1/ior, schlickOutside} (Glass):
+//                          per-material values of Sphere.fs:117,283-289; plane {albedo, fuzz, 0, 0}    32 B/object, global memory
 // Objects: bounded spheres first (tree leaves point at them), then the unbounded list in Scene.make order.
+// Order in the image: node | geo | meta | node32 | mat.  The counting kernel variant stages [node, meta end) into LDS, the timed
+// one [geo, node32 end).
 #ifndef RTD_NODE_BYTES
 #define RTD_NODE_BYTES 112
 #endif
+#define RTD_NODE32_BYTES 64
 #define RTD_LEAF 0x40000000 /* flag in on_hit / in a walk offset: a leaf's primitive test is pending */
 struct TexRec { // global memory only
     uint32_t kind;
@@ -260,9 +267,11 @@ template <bool LDS> struct SceneView {
 };
 
 struct SceneOffsets { // byte offsets into the image
-    uint32_t node, geo, meta, mat, total;
-    uint32_t lds_total; // node + geo + meta: what the LDS variant of the kernel stages
+    uint32_t node, geo, meta, node32, mat, total;
+    uint32_t lds_total;   // node + geo + meta: what the counting LDS variant of the kernel stages (from offset 0)
+    uint32_t lds32_total; // geo + meta + node32: what the timed LDS variant stages (from offset `geo`)
     int32_t n_nodes, n_bounded, n_unbounded;
+    float bmax;           // >= |every coordinate of every node32 box| and >= 1e-30: the scale of the filter's margin (walk_ctx32)
 };
 
 #define RTD_KIND_SPHERE 0u
@@ -445,6 +454,107 @@ RTD_INLINE int node_loop_lds(int off, uint32_t &pend, int end, int stop, V3 o, c
     return off;
 }
 #define RTD_PEND_MARK 0x4000u /* a queue entry is RTD_PEND_MARK | object: never zero, objects of an LDS-resident scene are < 16384 */
+
+// ---- the node loop of the timed variant: a conservative single-precision FILTER, the exact test left to the leaf pass -----------
+// Scene.bestCandidate tests a sphere iff the ray hits its Leaf box and every Branch box above it, and a ray that hits a Leaf box
+// hits every box that contains it (rt_scene.h, "the tree the device WALKS"): the spheres tested for a ray are {i : hits leafBox_i},
+// whatever stands above the leaves.  So the walk above the leaves may use ANY test F with  hits(box) => F(box)  for every box:
+//     tested set = {i : F(every box above leaf i) && F(leafBox_i) && hits(leafBox_i)} = {i : hits(leafBox_i)},
+// because hits(leafBox_i) => hits(every box above it) => F(every box above it).  F's false positives only cost visits.
+// F here: the slab test in single precision on boxes rounded OUTWARD (lo down, hi up; rt_scene.h) with every per-axis entry
+// distance pushed down and every exit distance pushed up by a margin that covers all rounding between the two computations:
+//     exact:   t = fl64(fl64(b - o) * fl64(1/d))                           = (b - o)/d * (1 + th),  |th| <= 3.1 * 2^-53
+//     filter:  t' = fl32(b32 * i + c),  i = rcp32(fl32(d)) = (1/d)(1 + k), |k| <= 3.01 e  (e = 2^-24; v_rcp_f32 is within 1 ulp)
+//              oi = fl32(fl32(o) * i) = (o/d)(1 + l), |l| <= 5.02 e;   c = fl32(-oi -+ m)
+//     => |t' - (b32 - o)/d| <= 4.1 e |b32/d| + 7.1 e |o/d| + underflow (< 1e-37)   when m = 0,
+// and (b32 - o)/d is on the safe side of (b - o)/d by the outward rounding (near: lo for d >= 0, hi for d < 0 -- the exact test's
+// own choice, BoundingBox.fs:52-55, keyed on the sign bit of d like the sign of fl64(1/d)).  The margin is
+//     m = fl32(fma(|i|, bmax, |oi|) * 2^-20 + 1e-30)  >=  16 e (|b32/d| + |o/d|)(1 - 8 e) + 1e-30        (bmax >= |b32| for every box),
+// more than twice what is needed.  Infinities and NaNs: +-inf or NaN anywhere in the chain makes m = inf or NaN, hence a lower
+// bound of -inf or NaN and an upper bound of +inf or NaN; v_max3/v_min3 return the non-NaN operand, v_max(x, 0) is never NaN, and
+// the final test is `not (tmax < tmin)`, true for a NaN tmax: such an axis (or ray) constrains nothing, as in the exact test,
+// whose NaN products leave tMin/tMax as they were.  The exact BoundingBox.hits of a Leaf box runs in the leaf pass
+// (leaf_test_object_exact), so no sphere is tested that the reference would not test.
+// tests: test_filter_is_conservative (CPU model, 1e8 cases incl. rays through edges and corners, origins on faces, axis-aligned and
+// denormal directions, huge and tiny boxes) and, on the GPU, rt_dev_bbox_filter over the same generators plus every render test
+// (the counting variant walks the exact double-precision records; every render test compares the two variants).
+struct WalkCtx32 {
+    float ix, iy, iz;    // ~ 1 / d
+    float cnx, cny, cnz; // entry distance of axis a is bounded below by fma(near32_a, i_a, cn_a)
+    float cfx, cfy, cfz; // exit distance above by fma(far32_a, i_a, cf_a)
+    int nX, nY, nZ;      // 0 or 8: byte offset of the (near, far) pair inside the axis' {lo, hi, hi, lo} quad of floats
+};
+RTD_INLINE void filter_axis(double o, double d, float bmax, float &inv, float &cn, float &cf, int &nOff) {
+    inv = __builtin_amdgcn_rcpf((float) d);
+    const float oi = (float) o * inv;
+    const float m = fmaf(__builtin_fabsf(inv), bmax, __builtin_fabsf(oi)) * 0x1p-20f + 1e-30f;
+    cn = -oi - m;
+    cf = m - oi;
+    nOff = (int) (((uint32_t) __double2hiint(d) >> 28) & 8u); // the sign bit of d, as 0 or 8
+}
+RTD_INLINE WalkCtx32 walk_ctx32(V3 o, V3 d, float bmax) {
+    WalkCtx32 c;
+    filter_axis(o.x, d.x, bmax, c.ix, c.cnx, c.cfx, c.nX);
+    filter_axis(o.y, d.y, bmax, c.iy, c.cny, c.cfy, c.nY);
+    filter_axis(o.z, d.z, bmax, c.iz, c.cnz, c.cfz, c.nZ);
+    return c;
+}
+// F for one box given as single-precision (lo, hi) pairs already rounded outward (unit hook and the CPU model's counterpart)
+RTD_INLINE bool bbox_filter(const WalkCtx32 &c, float lox, float hix, float loy, float hiy, float loz, float hiz) {
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(fmaf(c.nX ? hix : lox, c.ix, c.cnx), fmaf(c.nY ? hiy : loy, c.iy, c.cny)),
+                                                     fmaf(c.nZ ? hiz : loz, c.iz, c.cnz)), 0.0f);
+    const float tf = __builtin_fminf(__builtin_fminf(fmaf(c.nX ? lox : hix, c.ix, c.cfx), fmaf(c.nY ? loy : hiy, c.iy, c.cfy)), fmaf(c.nZ ? loz : hiz, c.iz, c.cfz));
+    return !(tf < tn);
+}
+// The loop itself, same shape as node_loop_lds: 18 VALU + 4 LDS instructions per visit, none of them double precision
+// (3 address adds, 3 ds_read_b64 + 1 ds_read_b128, 6 v_fma_f32, max3 / min3 / max, 1 compare, 2 selects, 1 v_alignbit, 2 for the
+// activity test) -- measured issue cost ~80 cycles per visit against ~147 for the double-precision loop (profiles/r3/valu_rates.txt).
+RTD_INLINE int node_loop_lds32(int off, uint32_t &pend, int end, int stop, const WalkCtx32 &c) {
+    int ax, ay, az, cnt;
+    unsigned long long save, save2;
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n"
+        "1:\n"
+        "  v_cmp_gt_i32 vcc, %[end], %[off]\n"
+        "  v_cmp_eq_u16 %[save2], 0, %[pend]\n"
+        "  s_and_b64 vcc, vcc, %[save2]\n"
+        "  s_bcnt1_i32_b64 %[cnt], vcc\n"
+        "  s_cmp_le_u32 %[cnt], %[stop]\n"
+        "  s_cbranch_scc1 2f\n"
+        "  s_and_saveexec_b64 %[save], vcc\n"
+        "  v_add_u32 %[ax], %[off], %[nx]\n"
+        "  v_add_u32 %[ay], %[off], %[ny]\n"
+        "  v_add_u32 %[az], %[off], %[nz]\n"
+        "  ds_read_b64 v[100:101], %[ax]\n"
+        "  ds_read_b64 v[102:103], %[ay] offset:16\n"
+        "  ds_read_b64 v[104:105], %[az] offset:32\n"
+        "  ds_read_b128 v[106:109], %[off] offset:48\n"
+        "  s_waitcnt lgkmcnt(3)\n"
+        "  v_fma_f32 v100, v100, %[ix], %[cnx]\n"
+        "  v_fma_f32 v101, v101, %[ix], %[cfx]\n"
+        "  s_waitcnt lgkmcnt(2)\n"
+        "  v_fma_f32 v102, v102, %[iy], %[cny]\n"
+        "  v_fma_f32 v103, v103, %[iy], %[cfy]\n"
+        "  s_waitcnt lgkmcnt(1)\n"
+        "  v_fma_f32 v104, v104, %[iz], %[cnz]\n"
+        "  v_fma_f32 v105, v105, %[iz], %[cfz]\n"
+        "  v_max3_f32 v100, v100, v102, v104\n"
+        "  v_min3_f32 v101, v101, v103, v105\n"
+        "  v_max_f32 v100, 0, v100\n"
+        "  v_cmp_nlt_f32 vcc, v101, v100\n"
+        "  s_waitcnt lgkmcnt(0)\n"
+        "  v_cndmask_b32 %[off], v107, v106, vcc\n"
+        "  v_cndmask_b32 v107, 0, v109, vcc\n"
+        "  v_alignbit_b32 %[pend], v108, %[pend], v107\n"
+        "  s_mov_b64 exec, %[save]\n"
+        "  s_branch 1b\n"
+        "2:\n"
+        : [off] "+v"(off), [pend] "+v"(pend), [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [cnt] "=&s"(cnt), [save] "=&s"(save), [save2] "=&s"(save2)
+        : [end] "s"(end), [stop] "s"(stop), [nx] "v"(c.nX), [ny] "v"(c.nY), [nz] "v"(c.nZ), [ix] "v"(c.ix), [iy] "v"(c.iy), [iz] "v"(c.iz),
+          [cnx] "v"(c.cnx), [cny] "v"(c.cny), [cnz] "v"(c.cnz), [cfx] "v"(c.cfx), [cfy] "v"(c.cfy), [cfz] "v"(c.cfz)
+        : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109");
+    return off;
+}
 // The oldest entry of a lane's queue (the low half if occupied, else the high half), removed from it.
 RTD_INLINE int pend_pop(uint32_t &pend) {
     const uint32_t lo = pend & 0xFFFFu;
@@ -470,6 +580,20 @@ RTD_INLINE void leaf_test(const SceneView<LDS> &sc, V3 o, V3 d, WalkCtx &c, Walk
 template <bool LDS>
 RTD_INLINE void leaf_test_object(const SceneView<LDS> &sc, V3 o, V3 d, WalkCtx &c, Walk &w, int prim) {
     const d2 g0 = sc.geo[prim * 3 + 0], g1 = sc.geo[prim * 3 + 1];
+    const double t = sphere_first_intersection(o, d, mk(g0.x, g0.y, g1.x), g1.y);
+    const double a = t * t;
+    if (a < c.bestF || (a == c.bestF && prim < w.best)) { c.bestF = a; w.best = prim; w.bestLen = t; }
+}
+// A leaf the single-precision filter let through (node_loop_lds32): first the leaf's own BoundingBox.hits, exactly (Scene.fs:41),
+// then the sphere.  The box is Sphere.make's (Sphere.fs:333-336): centre + (-radius) and centre + radius per axis, the same two IEEE
+// additions the host made (x - (-y) = x + y and x + (-y) = x - y exactly), near/far chosen by the sign of the inverse direction as
+// bbox_hits does.
+template <bool LDS>
+RTD_INLINE void leaf_test_object_exact(const SceneView<LDS> &sc, V3 o, V3 d, WalkCtx &c, Walk &w, int prim) {
+    const d2 g0 = sc.geo[prim * 3 + 0], g1 = sc.geo[prim * 3 + 1];
+    const double r = sc.geo[prim * 3 + 2].y;
+    const double rx = c.ix < 0.0 ? r : -r, ry = c.iy < 0.0 ? r : -r, rz = c.iz < 0.0 ? r : -r;
+    if (!bbox_hits_nf(c.ix, c.iy, c.iz, o, g0.x + rx, g0.x - rx, g0.y + ry, g0.y - ry, g1.x + rz, g1.x - rz)) return;
     const double t = sphere_first_intersection(o, d, mk(g0.x, g0.y, g1.x), g1.y);
     const double a = t * t;
     if (a < c.bestF || (a == c.bestF && prim < w.best)) { c.bestF = a; w.best = prim; w.bestLen = t; }
@@ -617,7 +741,7 @@ RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, 
         else act = ACT_LAMBERT_ONCE;
     } else {
         const V3 c = mk(g0.x, g0.y, g1.x);
-        const double r2 = g1.y, radius = m0;
+        const double r2 = g1.y, radius = g2.y;
         const bool flipped = (m.x >> 5) & 1; // Float.compare radius 0.0 = Less (Sphere.fs:321), set by the host
         if (!unitise(vsub(strike, c), n)) n = mk(0.0, 0.0, 0.0); // Sphere.normal (Sphere.fs:65-66)
         V3 co = vsub(c, o);
@@ -642,7 +766,7 @@ RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, 
             cosI = dot(vscale(-1.0, d), n);
             double r = rng_get(rng);
             invIor = p2;
-            const double param = inside ? g2.y : p3; // ((1 - sr) / (1 + sr))^2 for sr = 1/ior | ior (Sphere.fs:283-289), per material
+            const double param = inside ? m0 : p3; // ((1 - sr) / (1 + sr))^2 for sr = 1/ior | ior (Sphere.fs:283-289), per material
             double prob = param + (1.0 - param) * pow5(1.0 - cosI);
             act = (r < prob) ? ACT_REFLECT : ACT_REFRACT;
         }
@@ -724,6 +848,9 @@ RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, 
 // `fast_style` says which objects qualify (from the meta word alone).
 RTD_INLINE bool fast_style(i2 m) {
     const uint32_t ks = (uint32_t) m.x & 31u; // kind | style << 2
+#ifdef RTD_PARK_LAMBERT /* experiment (VERDICT r2 item 1's gate): park everything but the light sources */
+    return (((uint32_t) m.y) >> 24) == 0u && (ks == (RTD_KIND_SPHERE | (0u << 2)) || ks == (RTD_KIND_PLANE | (0u << 2)));
+#endif
     return (((uint32_t) m.y) >> 24) == 0u && (ks == (RTD_KIND_SPHERE | (0u << 2)) || ks == (RTD_KIND_SPHERE | (4u << 2)) || ks == (RTD_KIND_PLANE | (0u << 2)));
 }
 template <bool LDS>

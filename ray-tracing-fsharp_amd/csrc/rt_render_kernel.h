@@ -86,8 +86,9 @@ RTD_INLINE uint32_t lane_rank(unsigned long long mask) { // number of set bits o
     return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
 }
 
-template <bool LDS> RTD_INLINE SceneView<LDS> make_view(const RenderParams &p, const unsigned char *lds_base);
-template <> RTD_INLINE SceneView<true> make_view<true>(const RenderParams &p, const unsigned char *lds_base) {
+// F32: the LDS copy is the timed variant's -- geo | meta | node32 (stage_scene<.., true>), walked by node_loop_lds32
+template <bool LDS, bool F32 = false> RTD_INLINE SceneView<LDS> make_view(const RenderParams &p, const unsigned char *lds_base);
+template <> RTD_INLINE SceneView<true> make_view<true, false>(const RenderParams &p, const unsigned char *lds_base) {
     SceneView<true> v;
     const RTD_AS3 unsigned char *b = (const RTD_AS3 unsigned char *) lds_base;
     v.node = (Ptrs<true>::bp) (b + p.off.node);
@@ -99,7 +100,19 @@ template <> RTD_INLINE SceneView<true> make_view<true>(const RenderParams &p, co
     v.tex = p.tex; v.texels = p.texels;
     return v;
 }
-template <> RTD_INLINE SceneView<false> make_view<false>(const RenderParams &p, const unsigned char *) {
+template <> RTD_INLINE SceneView<true> make_view<true, true>(const RenderParams &p, const unsigned char *lds_base) {
+    SceneView<true> v;
+    const RTD_AS3 unsigned char *b = (const RTD_AS3 unsigned char *) lds_base - p.off.geo; // the copy starts at the image's `geo` section
+    v.node = (Ptrs<true>::bp) (b + p.off.node32);
+    v.geo = (Ptrs<true>::d2p) (b + p.off.geo);
+    v.meta = (Ptrs<true>::i2p) (b + p.off.meta);
+    v.mat = (const double *) (p.scene_image + p.off.mat);
+    v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
+    v.first = (int) (uint32_t) (uintptr_t) v.node; v.end = v.first + v.n_nodes * RTD_NODE32_BYTES;
+    v.tex = p.tex; v.texels = p.texels;
+    return v;
+}
+template <> RTD_INLINE SceneView<false> make_view<false, false>(const RenderParams &p, const unsigned char *) {
     SceneView<false> v;
     const unsigned char *b = p.scene_image;
     v.node = b + p.off.node;
@@ -271,11 +284,13 @@ struct Sched {
         WalkCtx c = walk_ctx(d, w); // cheap to re-derive; keeps 9 doubles out of the parked state
         const int stop = (nBusy - p.yield_lanes) > 0 ? (nBusy - p.yield_lanes) : 0; // active <= stop  <=>  waiting >= yield
         if constexpr (LDS && !COUNT) {
-            // the timed variant: the hand-written loop with its queue of pending leaf tests (rt_device.h); a lane is finished when its
-            // walk is exhausted AND its queue is empty
+            // the timed variant: the hand-written single-precision filter loop with its queue of pending leaves (rt_device.h); the
+            // leaf pass makes the leaf's exact box test and then the sphere's; a lane is finished when its walk is exhausted AND
+            // its queue is empty
+            const WalkCtx32 f = walk_ctx32(o, d, p.off.bmax);
             for (;;) {
-                w.off = node_loop_lds(w.off, pend, end, stop, o, c);
-                if (pend != 0u) leaf_test_object<LDS>(sc, o, d, c, w, pend_pop(pend));
+                w.off = node_loop_lds32(w.off, pend, end, stop, f);
+                if (pend != 0u) leaf_test_object_exact<LDS>(sc, o, d, c, w, pend_pop(pend));
                 const bool fin = (st == L_WALK) && (w.off >= end) && pend == 0u;
                 if (fin) st = L_DONE;
                 const int nWalk = __popcll(__builtin_amdgcn_ballot_w64(st == L_WALK));
@@ -544,31 +559,34 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
     }
 }
 
-// Stages the LDS part of the scene image (node, geo, meta) into the workgroup's LDS, 16 B per lane per trip, coalesced, and makes
-// the node links absolute LDS addresses: a walk position then IS the record's address (no add per visit).  Returns the bytes used.
-// QUEUE (the timed variant, node_loop_lds): a Leaf's on_hit link becomes its on_miss link (the walk goes on), the third link word its
-// queue entry RTD_PEND_MARK | object, the fourth the shift 16; a Branch gets 0 and 0 there.
-template <int BLOCK, bool QUEUE>
+// Stages the LDS part of the scene image into the workgroup's LDS, 16 B per lane per trip, coalesced, and makes the node links
+// absolute LDS addresses: a walk position then IS the record's address (no add per visit).  Returns the bytes used.
+// F32 = false (the counting variant): node | geo | meta, the exact double-precision records, walked by the compiled node_step.
+// F32 = true (the timed variant): geo | meta | node32, the single-precision filter records in their queue form (rt_scene.h),
+// walked by node_loop_lds32.
+template <int BLOCK, bool F32>
 RTD_INLINE uint32_t stage_scene(const RenderParams &p, unsigned char *smem) {
-    const uint32_t sceneBytes = p.off.lds_total;
-    const d2 *src = (const d2 *) p.scene_image;
+    const uint32_t sceneBytes = F32 ? p.off.lds32_total : p.off.lds_total;
+    const d2 *src = (const d2 *) (p.scene_image + (F32 ? p.off.geo : 0u));
     RTD_AS3 d2 *dst = (RTD_AS3 d2 *) smem;
     for (uint32_t i = threadIdx.x; i < sceneBytes / 16u; i += BLOCK) dst[i] = src[i];
     __syncthreads();
-    RTD_AS3 unsigned char *nodes = (RTD_AS3 unsigned char *) smem + p.off.node;
+    RTD_AS3 unsigned char *nodes = (RTD_AS3 unsigned char *) smem + (F32 ? p.off.node32 - p.off.geo : p.off.node);
     const int first = (int) (uint32_t) (uintptr_t) nodes;
     for (int i = threadIdx.x; i < p.off.n_nodes; i += BLOCK) {
-        RTD_AS3 i4 *lk = (RTD_AS3 i4 *) (nodes + i * RTD_NODE_BYTES + 96);
-        i4 v = *lk; // on_hit, on_miss, prim, 0
-        v.x += first; // a Leaf's RTD_LEAF flag (bit 30) is above every LDS address and survives the add
-        v.y += first;
-        if (QUEUE) {
-            const bool leaf = v.z >= 0;
-            if (leaf) v.x = v.y;
-            v.w = leaf ? 16 : 0;
-            v.z = leaf ? (int) (RTD_PEND_MARK | (uint32_t) v.z) : 0;
+        if (F32) {
+            RTD_AS3 i2 *lk = (RTD_AS3 i2 *) (nodes + i * RTD_NODE32_BYTES + 48);
+            i2 v = *lk; // on_hit, on_miss
+            v.x += first;
+            v.y += first;
+            *lk = v;
+        } else {
+            RTD_AS3 i2 *lk = (RTD_AS3 i2 *) (nodes + i * RTD_NODE_BYTES + 96);
+            i2 v = *lk;
+            v.x += first; // a Leaf's RTD_LEAF flag (bit 30) is above every LDS address and survives the add
+            v.y += first;
+            *lk = v;
         }
-        *lk = v;
     }
     __syncthreads();
     return sceneBytes;
@@ -589,7 +607,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     const uint32_t sceneBytes = LDS ? stage_scene<BLOCK, !COUNT>(p, smem) : 0u;
-    const SceneView<LDS> sc = make_view<LDS>(p, smem);
+    const SceneView<LDS> sc = make_view<LDS, LDS && !COUNT>(p, smem);
     const uint32_t P = (uint32_t) p.chunk;
     RTD_AS3 uint32_t *wv = (RTD_AS3 uint32_t *) (smem + sceneBytes) + (size_t) wave * (MODE == 1 ? RTD_WAVE_WORDS_A(P) : RTD_WAVE_WORDS(P));
     RTD_AS3 uint32_t *acc = wv;

@@ -458,6 +458,19 @@ static std::string build_scene(const rt_hittable *h, size_t n, const rt_texture 
     return std::string();
 }
 
+// Outward rounding of a box coordinate to single precision (the node32 records of the timed kernel's filter loop, rt_device.h):
+// the largest float <= v / the smallest float >= v.  +-inf and NaN pass through.
+static inline float f32_down(double v) {
+    float f = (float) v; // round to nearest
+    if ((double) f > v) f = std::nextafterf(f, -HUGE_VALF);
+    return f;
+}
+static inline float f32_up(double v) {
+    float f = (float) v;
+    if ((double) f < v) f = std::nextafterf(f, HUGE_VALF);
+    return f;
+}
+
 // The device image of s.walkTree and the object table (layout: rt_device.h).  Called again when the walk tree changes.
 static void encode_image(HostScene &s) {
     const rt_hittable *h = s.hittables.data();
@@ -465,23 +478,28 @@ static void encode_image(HostScene &s) {
     const FlatTree &wt = s.walkTree;
     const size_t nn = wt.skip.size();
 
-    // ---- device image ----
+    // ---- device image: node | geo | meta | node32 | mat ----
     rtd::SceneOffsets &off = s.off;
     size_t cur = 0;
     off.node = (uint32_t) cur; cur = align16(cur + nn * RTD_NODE_BYTES);
     off.geo = (uint32_t) cur;  cur = align16(cur + nobj * 48u);
     off.meta = (uint32_t) cur; cur = align16(cur + nobj * 8u);
-    off.lds_total = (uint32_t) cur; // what follows stays in global memory
+    off.lds_total = (uint32_t) cur; // [0, lds_total): what the counting variant stages
+    off.node32 = (uint32_t) cur; cur = align16(cur + nn * RTD_NODE32_BYTES);
+    off.lds32_total = (uint32_t) cur - off.geo; // [geo, node32 end): what the timed variant stages
     off.mat = (uint32_t) cur;  cur = align16(cur + nobj * 32u);
     off.total = (uint32_t) cur;
     off.n_nodes = (int32_t) nn; off.n_bounded = (int32_t) nb; off.n_unbounded = (int32_t) nu;
     s.image.assign(cur == 0 ? 16 : cur, 0);
     if (cur == 0) off.total = 16;
     if (off.lds_total == 0) off.lds_total = 16;
+    if (off.lds32_total == 0) off.lds32_total = 16;
     unsigned char *pnode = s.image.data() + off.node;
+    unsigned char *pnode32 = s.image.data() + off.node32;
     double *pgeo = (double *) (s.image.data() + off.geo);
     int32_t *pmeta = (int32_t *) (s.image.data() + off.meta);
     double *pmat = (double *) (s.image.data() + off.mat);
+    float bmax = 1e-30f;
     for (size_t i = 0; i < nn; ++i) {
         double *bx = (double *) (pnode + i * RTD_NODE_BYTES);
         int32_t *lk = (int32_t *) (pnode + i * RTD_NODE_BYTES + 96);
@@ -491,7 +509,24 @@ static void encode_image(HostScene &s) {
         lk[1] = onMiss;
         lk[2] = wt.prim[i]; // object index of a Leaf, -1 for a Branch
         lk[3] = 0;
+        // the filter loop's record: the box rounded outward, {lo, hi, hi, lo} per axis; links in the queue form of node_loop_lds32:
+        // a Leaf's on_hit is its on_miss (the walk goes on), the third word its queue entry, the fourth the shift that pushes it
+        float *fx = (float *) (pnode32 + i * RTD_NODE32_BYTES);
+        int32_t *lk32 = (int32_t *) (pnode32 + i * RTD_NODE32_BYTES + 48);
+        for (int a = 0; a < 3; ++a) {
+            const float lo = f32_down(wt.box[i].mn[a]), hi = f32_up(wt.box[i].mx[a]);
+            fx[a * 4] = lo; fx[a * 4 + 1] = hi; fx[a * 4 + 2] = hi; fx[a * 4 + 3] = lo;
+            if (std::fabs(lo) > bmax) bmax = std::fabs(lo); // (a NaN coordinate compares false and leaves bmax alone; it makes its own products NaN)
+            if (std::fabs(hi) > bmax) bmax = std::fabs(hi);
+        }
+        const bool leaf = wt.prim[i] >= 0;
+        const int32_t onMiss32 = wt.skip[i] * RTD_NODE32_BYTES;
+        lk32[0] = leaf ? onMiss32 : (int32_t) ((i + 1) * RTD_NODE32_BYTES);
+        lk32[1] = onMiss32;
+        lk32[2] = leaf ? (int32_t) (RTD_PEND_MARK | (uint32_t) wt.prim[i]) : 0;
+        lk32[3] = leaf ? 16 : 0;
     }
+    off.bmax = bmax;
     for (size_t j = 0; j < nobj; ++j) {
         const rt_hittable &o = h[(size_t) s.objToOrig[j]];
         double *g = pgeo + j * 6;
@@ -504,12 +539,12 @@ static void encode_image(HostScene &s) {
         } else {
             g[0] = o.point[0]; g[1] = o.point[1]; g[2] = o.point[2];
             g[3] = o.radius * o.radius; // RadiusSquared (Sphere.fs:326)
-            g[4] = o.albedo; g[5] = 0.0; // the radius itself (LightSourceCap only) is in `mat`
+            g[4] = o.albedo; g[5] = o.radius; // the radius itself: LightSourceCap (Sphere.fs:191) and the leaf pass' exact box (leaf_test_object_exact)
             // flipped = Float.compare this.Radius 0.0 = Less (Sphere.fs:321)
             const bool flipped = !(std::fabs(o.radius - 0.0) < 0.00000001) && (o.radius < 0.0);
             m0 = RTD_KIND_SPHERE | (o.style << 2) | (flipped ? 32u : 0u);
             const bool usesIor = o.style == RT_SPHERE_DIELECTRIC || o.style == RT_SPHERE_GLASS;
-            pmat[j * 4 + 0] = o.radius; pmat[j * 4 + 1] = usesIor ? o.ior : o.fuzz; pmat[j * 4 + 2] = o.prob; pmat[j * 4 + 3] = 0.0;
+            pmat[j * 4 + 0] = 0.0; pmat[j * 4 + 1] = usesIor ? o.ior : o.fuzz; pmat[j * 4 + 2] = o.prob; pmat[j * 4 + 3] = 0.0;
             if (usesIor) {
                 // Per-material values the reference recomputes at every hit from the same inputs with the same IEEE operations
                 // (this translation unit is built with -ffp-contract=off): `1.0 / ior` (Sphere.fs:117, 283-284) and Schlick's
@@ -519,9 +554,9 @@ static void encode_image(HostScene &s) {
                 if (o.style == RT_SPHERE_DIELECTRIC) pmat[j * 4 + 3] = inv;
                 else {
                     const double po = (1.0 - ior) / (1.0 + ior), pi = (1.0 - inv) / (1.0 + inv);
+                    pmat[j * 4 + 0] = pi * pi;  // Schlick's term inside the glass
                     pmat[j * 4 + 2] = inv;      // Glass carries no refraction probability
                     pmat[j * 4 + 3] = po * po;
-                    g[5] = pi * pi;             // the sphere record's spare double
                 }
             }
         }

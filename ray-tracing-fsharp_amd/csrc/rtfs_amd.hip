@@ -138,8 +138,10 @@ static const char *check_settings(const Settings &s) {
     if (s.park < -1 || s.park > RTD_MAX_PARK) return "park_lanes must be in [-1, 256]";
     return nullptr;
 }
-static size_t lds_need(const rth::HostScene &h, bool lds, int block, int chunk, bool passA = false) {
-    return (lds ? (size_t) h.off.lds_total : 0u) + (size_t) (block / 64) * (passA ? RTD_WAVE_WORDS_A(chunk) : RTD_WAVE_WORDS(chunk)) * 4u;
+// `count`: the counting kernel variant stages the exact double-precision node records (112 B), the timed one the single-precision
+// filter records (64 B)
+static size_t lds_need(const rth::HostScene &h, bool lds, bool count, int block, int chunk, bool passA = false) {
+    return (lds ? (size_t) (count ? h.off.lds_total : h.off.lds32_total) : 0u) + (size_t) (block / 64) * (passA ? RTD_WAVE_WORDS_A(chunk) : RTD_WAVE_WORDS(chunk)) * 4u;
 }
 struct LaunchPlan {
     int block = 1024, chunk = 16, park = 0;
@@ -147,13 +149,13 @@ struct LaunchPlan {
 };
 // Block size and residency for a scene: the preferred block if the LDS image fits beside the waves' scratch, else 256
 // threads if that fits, else the global-memory variant of the kernel at the preferred block.
-static LaunchPlan plan_launch(const rth::HostScene &h, const Settings &s) {
+static LaunchPlan plan_launch(const rth::HostScene &h, const Settings &s, bool count = false) {
     LaunchPlan p;
     p.block = s.block ? s.block : 1024;
     p.chunk = s.chunk ? s.chunk : 16;
     p.park = s.park < 0 ? 0 : (s.park ? s.park : RTD_PARK_DEFAULT);
     // (an LDS-resident scene has far fewer than the 16384 objects the node loop's 14-bit queue entries can name: 48 B each of 160 KiB)
-    auto fits = [&](int block, int chunk) { return h.nBounded + h.nUnbounded < 16384u && lds_need(h, true, block, chunk) <= RT_LDS_BYTES; };
+    auto fits = [&](int block, int chunk) { return h.nBounded + h.nUnbounded < 16384u && lds_need(h, true, count, block, chunk) <= RT_LDS_BYTES; };
     if (fits(p.block, p.chunk)) { p.lds = true; return p; }
     if (p.block > 256 && fits(256, p.chunk)) { p.block = 256; p.lds = true; return p; }
     return p; // global-memory variant: LDS holds only the waves' scratch, which always fits
@@ -418,10 +420,10 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
     const rth::HostScene &h = scene->host;
     hipStream_t st = (hipStream_t) stream;
 
-    const LaunchPlan plan = plan_launch(h, set);
+    const bool count = (flags & RT_RENDER_COUNTERS) != 0;
+    const LaunchPlan plan = plan_launch(h, set, count);
     const int block = plan.block, chunk = plan.chunk;
     const bool lds = plan.lds;
-    const bool count = (flags & RT_RENDER_COUNTERS) != 0;
 
     RenderParams p{};
     CameraParams hostCam{};
@@ -458,7 +460,7 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
 
     const bool tex = !h.texRecs.empty();
     render_fn fn = pick_kernel(lds, count, block, 0, tex);
-    const size_t ldsBytes = lds_need(h, lds, block, chunk);
+    const size_t ldsBytes = lds_need(h, lds, count, block, chunk);
     HIP_TRY(hipFuncSetAttribute((const void *) fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes));
     int perCu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, (const void *) fn, block, ldsBytes));
@@ -530,9 +532,9 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
             }
             // both passes must fit the LDS beside the scene image, decided BEFORE anything is launched (a misfit found after
             // pass A would leave a half-rendered buffer); 
-            while (lds && chunkA > 1 && lds_need(h, true, block, chunkA, true) > RT_LDS_BYTES) chunkA /= 2;
-            while (lds && chunkB > 1 && lds_need(h, true, block, chunkB) > RT_LDS_BYTES) chunkB /= 2;
-            const size_t ldsA = lds_need(h, lds, block, chunkA, true), ldsB = lds_need(h, lds, block, chunkB);
+            while (lds && chunkA > 1 && lds_need(h, true, count, block, chunkA, true) > RT_LDS_BYTES) chunkA /= 2;
+            while (lds && chunkB > 1 && lds_need(h, true, count, block, chunkB) > RT_LDS_BYTES) chunkB /= 2;
+            const size_t ldsA = lds_need(h, lds, count, block, chunkA, true), ldsB = lds_need(h, lds, count, block, chunkB);
             if (lds && (ldsA > RT_LDS_BYTES || ldsB > RT_LDS_BYTES)) return fail(RT_ERR_HIP, "two-pass launch does not fit the LDS");
             HIP_TRY(hipFuncSetAttribute((const void *) fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsA));
             HIP_TRY(hipFuncSetAttribute((const void *) fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsB));
@@ -1122,12 +1124,13 @@ __global__ void k_hit_object(const RenderParams p, int n, const double *rays, in
     }
     if (counters) { counters[i * 2] = cnt.aabb; counters[i * 2 + 1] = cnt.prim; }
 }
-// Scene.hitObject as the render kernel's timed variant runs it: scene staged into LDS, the hand-written node loop
-// (node_loop_lds), leaf tests between its runs, the unbounded objects last.  One ray per lane, 1024 rays per workgroup.
+// Scene.hitObject as the render kernel's timed variant runs it: scene staged into LDS, the hand-written single-precision filter
+// loop (node_loop_lds32), the leaf pass with the exact box and sphere tests between its runs, the unbounded objects last.  One ray
+// per lane, 1024 rays per workgroup.
 __global__ void __launch_bounds__(1024) k_hit_object_lds(const RenderParams p, int n, const double *rays, int32_t *hit, double *strike) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     (void) stage_scene<1024, true>(p, smem);
-    const SceneView<true> sc = make_view<true>(p, smem);
+    const SceneView<true> sc = make_view<true, true>(p, smem);
     const int i = blockIdx.x * 1024 + threadIdx.x;
     const bool valid = i < n;
     const double *r = rays + (size_t) (valid ? i : 0) * 6;
@@ -1136,11 +1139,12 @@ __global__ void __launch_bounds__(1024) k_hit_object_lds(const RenderParams p, i
     walk_begin(w, sc.first);
     if (!valid) w.off = sc.end;
     WalkCtx c = walk_ctx(d, w);
+    const WalkCtx32 f = walk_ctx32(o, d, p.off.bmax);
     uint32_t pend = 0u;
     for (;;) {
-        w.off = node_loop_lds(w.off, pend, sc.end, 0, o, c); // until no lane of the wave can step: walks exhausted or queues full
+        w.off = node_loop_lds32(w.off, pend, sc.end, 0, f); // until no lane of the wave can step: walks exhausted or queues full
         if (__builtin_amdgcn_ballot_w64(pend != 0u) == 0ull) break;
-        if (pend != 0u) leaf_test_object<true>(sc, o, d, c, w, pend_pop(pend));
+        if (pend != 0u) leaf_test_object_exact<true>(sc, o, d, c, w, pend_pop(pend));
     }
     Counters cnt; cnt.rays = cnt.aabb = cnt.prim = cnt.refl = 0;
     unbounded_tests<true, false>(sc, o, d, w, cnt);
@@ -1149,6 +1153,31 @@ __global__ void __launch_bounds__(1024) k_hit_object_lds(const RenderParams p, i
     const V3 sp = walk(o, d, w.bestLen);
     const double nanv = __builtin_nan("");
     strike[i * 3] = w.best < 0 ? nanv : sp.x; strike[i * 3 + 1] = w.best < 0 ? nanv : sp.y; strike[i * 3 + 2] = w.best < 0 ? nanv : sp.z;
+}
+// The single-precision filter of the timed node loop next to the exact test, box by box: out[i] = exact | filter << 1.
+// Boxes arrive as (min, max) doubles; the host rounds them outward exactly as the scene image does (rth::f32_down / f32_up).
+__global__ void k_bbox_filter(int n, const double *rays, const double *boxes, const float *boxes32, float bmax, int32_t *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *r = rays + i * 6, *b = boxes + i * 6;
+    const float *f = boxes32 + i * 6;
+    d2 bx, by, bz;
+    bx.x = b[0]; bx.y = b[3]; by.x = b[1]; by.y = b[4]; bz.x = b[2]; bz.y = b[5];
+    const V3 o = mk(r[0], r[1], r[2]), d = mk(r[3], r[4], r[5]);
+    const bool exact = bbox_hits(1.0 / d.x, 1.0 / d.y, 1.0 / d.z, o, bx, by, bz);
+    const WalkCtx32 c = walk_ctx32(o, d, bmax);
+    // the loop's own instruction forms (v_max3 / v_min3 / v_max / v_cmp_nlt): NaN handling is theirs
+    const float nx = c.nX ? f[3] : f[0], fx = c.nX ? f[0] : f[3], ny = c.nY ? f[4] : f[1], fy = c.nY ? f[1] : f[4], nz = c.nZ ? f[5] : f[2], fz = c.nZ ? f[2] : f[5];
+    float t0 = nx, t1 = fx, t2 = ny, t3 = fy, t4 = nz, t5 = fz;
+    unsigned long long m;
+    asm volatile("v_fma_f32 %0, %0, %7, %10\n\tv_fma_f32 %1, %1, %7, %13\n\t"
+                 "v_fma_f32 %2, %2, %8, %11\n\tv_fma_f32 %3, %3, %8, %14\n\t"
+                 "v_fma_f32 %4, %4, %9, %12\n\tv_fma_f32 %5, %5, %9, %15\n\t"
+                 "v_max3_f32 %0, %0, %2, %4\n\tv_min3_f32 %1, %1, %3, %5\n\tv_max_f32 %0, 0, %0\n\tv_cmp_nlt_f32_e64 %6, %1, %0"
+                 : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "=s"(m)
+                 : "v"(c.ix), "v"(c.iy), "v"(c.iz), "v"(c.cnx), "v"(c.cny), "v"(c.cnz), "v"(c.cfx), "v"(c.cfy), "v"(c.cfz));
+    const bool filter = (m >> (threadIdx.x & 63)) & 1ull;
+    out[i] = (exact ? 1 : 0) | (filter ? 2 : 0) | (bbox_filter(c, f[0], f[3], f[1], f[4], f[2], f[5]) ? 4 : 0);
 }
 __global__ void k_trace_ray(const RenderParams p, int depth, int n, const double *rays, uint32_t *rng, uint8_t *col_out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1229,6 +1258,31 @@ int rt_dev_bbox_hits(int32_t device, int32_t n, const double *rays, const double
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(dh.down(hit_out));
+    return RT_OK;
+}
+
+int rt_dev_bbox_filter(int32_t device, int32_t n, const double *rays, const double *boxes, double bmax, int32_t *out) {
+    if (!rays || !boxes || !out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard;
+    int rc = guard.enter(device);
+    if (rc != RT_OK) return rc;
+    std::vector<float> b32((size_t) n * 6);
+    float bm = 1e-30f; // as encode_image: >= every |coordinate| of the batch's rounded boxes, unless the caller names a larger scale
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            const float lo = rth::f32_down(boxes[(size_t) i * 6 + a]), hi = rth::f32_up(boxes[(size_t) i * 6 + 3 + a]);
+            b32[(size_t) i * 6 + a] = lo; b32[(size_t) i * 6 + 3 + a] = hi;
+            if (std::fabs(lo) > bm) bm = std::fabs(lo);
+            if (std::fabs(hi) > bm) bm = std::fabs(hi);
+        }
+    if (bmax > (double) bm) bm = rth::f32_up(bmax);
+    DevBuf<double> dr, db; DevBuf<float> df; DevBuf<int32_t> dh;
+    HIP_TRY(dr.alloc((size_t) n * 6)); HIP_TRY(db.alloc((size_t) n * 6)); HIP_TRY(df.alloc((size_t) n * 6)); HIP_TRY(dh.alloc((size_t) n));
+    HIP_TRY(dr.up(rays)); HIP_TRY(db.up(boxes)); HIP_TRY(df.up(b32.data()));
+    if (n) hipLaunchKernelGGL(k_bbox_filter, dim3(blocks_for(n)), dim3(256), 0, 0, n, dr.p, db.p, df.p, bm, dh.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dh.down(out));
     return RT_OK;
 }
 
@@ -1357,8 +1411,8 @@ int rt_dev_hit_object_lds(int32_t device, const rt_scene *scene, int32_t n, cons
     DeviceGuard guard;
     int rc = hook_scene_params(guard, device, scene, p);
     if (rc != RT_OK) return rc;
-    const size_t ldsBytes = scene->host.off.lds_total;
-    if (ldsBytes > RT_LDS_BYTES) return fail(RT_ERR_UNSUPPORTED, "the scene does not fit the LDS");
+    const size_t ldsBytes = scene->host.off.lds32_total;
+    if (ldsBytes > RT_LDS_BYTES || scene->host.nBounded + scene->host.nUnbounded >= 16384u) return fail(RT_ERR_UNSUPPORTED, "the scene does not fit the LDS");
     DevBuf<double> dr, dsk; DevBuf<int32_t> dh;
     HIP_TRY(dr.alloc((size_t) n * 6)); HIP_TRY(dh.alloc((size_t) n)); HIP_TRY(dsk.alloc((size_t) n * 3));
     HIP_TRY(dr.up(rays));

@@ -34,6 +34,15 @@ def bbox_hits(rays, boxes, device=0):
     return out
 
 
+def bbox_filter(rays, boxes, bmax=0.0, device=0):
+    """bit 0: BoundingBox.hits, exactly; bit 1: the timed node loop's single-precision filter (its own instructions); bit 2: the same
+    filter as compiled C++.  The filter must say 'hit' wherever the exact test does."""
+    rays, boxes = _c(rays, np.float64).reshape(-1, 6), _c(boxes, np.float64).reshape(-1, 6)
+    out = np.zeros(len(rays), np.int32)
+    check(lib.rt_dev_bbox_filter(device, len(rays), _f64(rays), _f64(boxes), float(bmax), _i32(out)))
+    return out
+
+
 def sphere_first_intersection(rays, spheres, device=0):
     rays, spheres = _c(rays, np.float64).reshape(-1, 6), _c(spheres, np.float64).reshape(-1, 4)
     out = np.zeros(len(rays), np.float64)

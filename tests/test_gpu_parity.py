@@ -99,6 +99,29 @@ def test_bbox_hits_incl_axis_aligned_rays(rt, orc):
     assert np.array_equal(rt.hooks.bbox_hits(rays, boxes), orc.bbox_hits(rays, boxes))
 
 
+def test_single_precision_filter_never_loses_a_hit(rt):
+    """The timed node loop's filter (csrc/rt_device.h) against the exact BoundingBox.hits, both on the device: exact hit => filter hit,
+    for the loop's own instruction forms (bit 1) and the compiled form (bit 2), on the cases of tests/filter_cases.py -- rays through
+    faces / edges / corners, origins on faces and corners, axis-aligned / denormal / non-unit directions, inverted and flat boxes,
+    coordinates from 1e-3 to 1e6, origins 1e13 away, NaN and infinite rays and boxes -- and with the margin's scale enlarged as a
+    whole tree's would be.  (The CPU model of the same filter is held to the ORACLE's exact test in tests/test_filter_conservative.py.)"""
+    import filter_cases as fc
+    n = 200_000
+    hits = 0
+    for name, rays, boxes in fc.classes(n, seed=31337):
+        for bmax in (0.0, 2000.0):
+            out = rt.hooks.bbox_filter(rays, boxes, bmax=bmax)
+            exact, loop, compiled = (out & 1) != 0, (out & 2) != 0, (out & 4) != 0
+            lost = exact & ~(loop & compiled)
+            assert not lost.any(), f"{name} (bmax {bmax}): the filter lost {int(lost.sum())} of {int(exact.sum())} hits, first at {int(np.flatnonzero(lost)[0])}"
+            if np.isfinite(rays).all() and np.isfinite(boxes).all():
+                assert np.array_equal(loop, compiled), name  # the two forms differ only in how NaN operands fall through min/max
+        hits += int(exact.sum())
+        if name.startswith(("random_scale2_", "random_scale10_")):  # it IS a filter: ordinary boxes the exact test rejects, it rejects
+            assert int((loop & ~exact).sum()) <= n // 2000, name
+    assert hits > 4_000_000
+
+
 def test_sphere_and_plane_intersection(rt, orc):
     rays = scenes.random_rays(200000, 21)
     rng = np.random.default_rng(22)
