@@ -141,7 +141,10 @@ typedef struct rt_scene_info {
     int64_t texel_bytes;
     int32_t walk_tree_nodes; /* nodes of the tree the device image holds: the size of rt_scene_get_walk_tree's arrays (= n_nodes
                                 until rt_scene_tune thins the tree) */
-    int32_t reserved;
+    int32_t leaf_box_implied; /* 1: the scene meets the bounds under which the timed kernel's leaf pass need not evaluate a Leaf's own
+                                 BoundingBox.hits when Sphere.firstIntersection has found a hit (csrc/rt_device.h,
+                                 leaf_test_object_exact: every bounded radius in (0, 100], coordinates within 1000, r_max * extent <= 500);
+                                 0: the leaf pass evaluates it for every candidate.  Diagnostic; results never depend on it. */
 } rt_scene_info;
 
 /* Scene.make (Scene.fs:15-28): partitions bounded/unbounded, builds the BoundingBoxTree on the host,

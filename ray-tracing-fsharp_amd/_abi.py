@@ -60,7 +60,7 @@ class rt_scene_info(C.Structure):
     _fields_ = [
         ("n_bounded", C.c_int32), ("n_unbounded", C.c_int32), ("n_nodes", C.c_int32), ("tree_depth", C.c_int32),
         ("n_textures", C.c_int32), ("lds_resident", C.c_int32), ("walk_tree", C.c_int32), ("walk_tree_depth", C.c_int32),
-        ("scene_bytes", C.c_int64), ("texel_bytes", C.c_int64), ("walk_tree_nodes", C.c_int32), ("reserved", C.c_int32),
+        ("scene_bytes", C.c_int64), ("texel_bytes", C.c_int64), ("walk_tree_nodes", C.c_int32), ("leaf_box_implied", C.c_int32),
     ]
 
 

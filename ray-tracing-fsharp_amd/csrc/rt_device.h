@@ -272,6 +272,7 @@ struct SceneOffsets { // byte offsets into the image
     uint32_t lds32_total; // geo + meta + node32: what the timed LDS variant stages (from offset `geo`)
     int32_t n_nodes, n_bounded, n_unbounded;
     float bmax;           // >= |every coordinate of every node32 box| and >= 1e-30: the scale of the filter's margin (walk_ctx32)
+    int32_t box_implied;  // 1: every bounded sphere has 0 < radius <= 100, bmax <= 1000 and radius_max * bmax <= 500 (leaf_test_object_exact)
 };
 
 #define RTD_KIND_SPHERE 0u
@@ -512,6 +513,11 @@ RTD_INLINE bool bbox_filter(const WalkCtx32 &c, float lox, float hix, float loy,
 RTD_INLINE int node_loop_lds32(int off, uint32_t &pend, int end, int stop, const WalkCtx32 &c) {
     int ax, ay, az, cnt;
     unsigned long long save, save2;
+#ifdef RTD_PK_FMA
+    auto pk = [](float lo, float hi) { return ((unsigned long long) __float_as_uint(hi) << 32) | (unsigned long long) __float_as_uint(lo); };
+    const unsigned long long pix = pk(c.ix, c.ix), piy = pk(c.iy, c.iy), piz = pk(c.iz, c.iz);
+    const unsigned long long pcx = pk(c.cnx, c.cfx), pcy = pk(c.cny, c.cfy), pcz = pk(c.cnz, c.cfz);
+#endif
     asm volatile(
         "s_waitcnt lgkmcnt(0)\n"
         "1:\n"
@@ -530,6 +536,13 @@ RTD_INLINE int node_loop_lds32(int off, uint32_t &pend, int end, int stop, const
         "  ds_read_b64 v[104:105], %[az] offset:32\n"
         "  ds_read_b128 v[106:109], %[off] offset:48\n"
         "  s_waitcnt lgkmcnt(3)\n"
+#ifdef RTD_PK_FMA /* (near, far) of an axis in one packed instruction: the inverse direction's low half serves both */
+        "  v_pk_fma_f32 v[100:101], v[100:101], %[pix], %[pcx] op_sel_hi:[1,0,1]\n"
+        "  s_waitcnt lgkmcnt(2)\n"
+        "  v_pk_fma_f32 v[102:103], v[102:103], %[piy], %[pcy] op_sel_hi:[1,0,1]\n"
+        "  s_waitcnt lgkmcnt(1)\n"
+        "  v_pk_fma_f32 v[104:105], v[104:105], %[piz], %[pcz] op_sel_hi:[1,0,1]\n"
+#else
         "  v_fma_f32 v100, v100, %[ix], %[cnx]\n"
         "  v_fma_f32 v101, v101, %[ix], %[cfx]\n"
         "  s_waitcnt lgkmcnt(2)\n"
@@ -538,6 +551,7 @@ RTD_INLINE int node_loop_lds32(int off, uint32_t &pend, int end, int stop, const
         "  s_waitcnt lgkmcnt(1)\n"
         "  v_fma_f32 v104, v104, %[iz], %[cnz]\n"
         "  v_fma_f32 v105, v105, %[iz], %[cfz]\n"
+#endif
         "  v_max3_f32 v100, v100, v102, v104\n"
         "  v_min3_f32 v101, v101, v103, v105\n"
         "  v_max_f32 v100, 0, v100\n"
@@ -552,6 +566,9 @@ RTD_INLINE int node_loop_lds32(int off, uint32_t &pend, int end, int stop, const
         : [off] "+v"(off), [pend] "+v"(pend), [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [cnt] "=&s"(cnt), [save] "=&s"(save), [save2] "=&s"(save2)
         : [end] "s"(end), [stop] "s"(stop), [nx] "v"(c.nX), [ny] "v"(c.nY), [nz] "v"(c.nZ), [ix] "v"(c.ix), [iy] "v"(c.iy), [iz] "v"(c.iz),
           [cnx] "v"(c.cnx), [cny] "v"(c.cny), [cnz] "v"(c.cnz), [cfx] "v"(c.cfx), [cfy] "v"(c.cfy), [cfz] "v"(c.cfz)
+#ifdef RTD_PK_FMA
+          , [pix] "v"(pix), [piy] "v"(piy), [piz] "v"(piz), [pcx] "v"(pcx), [pcy] "v"(pcy), [pcz] "v"(pcz)
+#endif
         : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109");
     return off;
 }
@@ -584,19 +601,57 @@ RTD_INLINE void leaf_test_object(const SceneView<LDS> &sc, V3 o, V3 d, WalkCtx &
     const double a = t * t;
     if (a < c.bestF || (a == c.bestF && prim < w.best)) { c.bestF = a; w.best = prim; w.bestLen = t; }
 }
-// A leaf the single-precision filter let through (node_loop_lds32): first the leaf's own BoundingBox.hits, exactly (Scene.fs:41),
-// then the sphere.  The box is Sphere.make's (Sphere.fs:333-336): centre + (-radius) and centre + radius per axis, the same two IEEE
-// additions the host made (x - (-y) = x + y and x + (-y) = x - y exactly), near/far chosen by the sign of the inverse direction as
-// bbox_hits does.
+// A leaf the single-precision filter let through (node_loop_lds32).  The reference tests the sphere iff the ray hits the leaf's own
+// box (Scene.fs:41), so a sphere hit found here counts only if BoundingBox.hits(leaf box) holds -- exactly.  That test is IMPLIED by
+// the sphere hit itself in all but a sliver of cases, and is evaluated only in that sliver:
+//   Claim.  Let the scene satisfy  0 < r <= 100 for every bounded sphere,  |every box coordinate| <= bmax <= 1000  and
+//   r_max * bmax <= 500  (SceneOffsets::box_implied, set by the host), let d be a unitised direction (|d|^2 = 1 +- 4 ulp: every ray of the render kernel),
+//   let dd = |o - c|^2 <= 1e6, and let Sphere.firstIntersection return t > 1e-8 from its Greater branch (computed discriminant
+//   >= 1e-8).  Then BoundingBox.hits of the box {c - r, c + r} (each corner rounded once, as Sphere.make forms it) evaluates to true.
+//   Proof.  In real arithmetic on the given doubles write disc' for the true discriminant; the computed one differs by at most
+//   6 ulp of (b^2 + dd + r^2) + dd * | |d|^2 - 1 | <= 2.3e-9, so disc' >= 7.7e-9.  Every computed slab distance
+//   fl(fl(face - o_a) * fl(1/d_a)) is within E * |1/d_a| of the real ((c_a +- r) - o_a) / d_a with
+//   E = 3.5e-16 * (|o_a - c_a| + r) + 1.2e-16 * (|c_a| + r) <= 5.05e-13 (three roundings, and the face's own rounding).
+//   (A) origin on or outside the sphere: both roots are positive, so the chord's midpoint parameter tm is > 0; the midpoint lies
+//   within sqrt(r^2 - disc') of the centre, i.e. inside the box by mu = r - sqrt(r^2 - disc') >= disc' / (2 r) >= 3.8e-11 on every
+//   axis; hence near_a <= tm - (mu - E)|1/d_a| and far_a >= tm + (mu - E)|1/d_a| as computed, mu - E > 0: tMax >= tMin, tMax > 0
+//   (also after the y stage).  (B) origin strictly inside: the roots t1 < 0 < t2 satisfy |t1| t2 = -cc / |d|^2 with t2 > 1e-8 - 1e-12
+//   and |t1| >= sqrt(disc') >= 8.7e-5, so the origin is rho = r - |o - c| >= -cc / (2 r) >= 4.3e-13 / r deep, inside the box by rho on
+//   every axis, and rho > 1.2e-16 * bmax (the faces' rounding) because r * bmax <= 500: every computed near distance is <= 0 (or
+//   -inf, NaN for d_a = 0: ignored), every far distance > 0: tMin = 0 < tMax.  Axis-aligned directions: the differences face - o_a
+//   are non-zero with the right sign by the same margins, so the products are +-inf of the right sign.  QED.
+// Outside the claim's hypotheses (the Equal branch |disc| < 1e-8, a far-away origin, a scene with huge or negative radii) the
+// candidate's box test is made exactly: the box is Sphere.make's (Sphere.fs:333-336), centre + (-radius) and centre + radius per axis,
+// the same two IEEE additions the host made (x - (-y) = x + y and x + (-y) = x - y exactly), near/far chosen by the sign of the
+// inverse direction as bbox_hits does.  Tests: every render test compares this variant with the counting one, which runs the exact
+// test on every leaf; test_leaf_box_is_implied_by_the_sphere_hit aims rays at the poles and the silhouettes of spheres.
+#define RTD_IMPLIED_DD 1.0e6
 template <bool LDS>
-RTD_INLINE void leaf_test_object_exact(const SceneView<LDS> &sc, V3 o, V3 d, WalkCtx &c, Walk &w, int prim) {
+RTD_INLINE void leaf_test_object_exact(const SceneView<LDS> &sc, V3 o, V3 d, double &bestF, Walk &w, int prim, bool implied) {
     const d2 g0 = sc.geo[prim * 3 + 0], g1 = sc.geo[prim * 3 + 1];
-    const double r = sc.geo[prim * 3 + 2].y;
-    const double rx = c.ix < 0.0 ? r : -r, ry = c.iy < 0.0 ? r : -r, rz = c.iz < 0.0 ? r : -r;
-    if (!bbox_hits_nf(c.ix, c.iy, c.iz, o, g0.x + rx, g0.x - rx, g0.y + ry, g0.y - ry, g1.x + rz, g1.x - rz)) return;
-    const double t = sphere_first_intersection(o, d, mk(g0.x, g0.y, g1.x), g1.y);
+    // Sphere.firstIntersection (sphere_first_intersection above, statement for statement; dd and the branch are needed below)
+    const V3 diff = vsub(o, mk(g0.x, g0.y, g1.x));
+    const double b = dot(d, diff);
+    const double dd = dot(diff, diff);
+    const double cc = dd - g1.y;
+    const double disc = (b * b - cc);
+    const int cmp = fcmp(disc, 0.0);
+    double t = __builtin_nan("");
+    if (cmp == CMP_EQ) { const double i = (-b); t = fpos(i) ? i : t; }
+    else if (cmp == CMP_GT) {
+        const double s = sqrt_above_tol(disc);
+        const double i1 = s - b, i2 = -(b + s);
+        t = fpos(i2) ? i2 : (fpos(i1) ? i1 : t);
+    }
     const double a = t * t;
-    if (a < c.bestF || (a == c.bestF && prim < w.best)) { c.bestF = a; w.best = prim; w.bestLen = t; }
+    bool cand = a < bestF || (a == bestF && prim < w.best);
+    if (cand && !(implied && cmp == CMP_GT && dd <= RTD_IMPLIED_DD)) { // the sliver: the leaf's BoundingBox.hits, exactly
+        const double r = sc.geo[prim * 3 + 2].y;
+        const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z;
+        const double rx = ix < 0.0 ? r : -r, ry = iy < 0.0 ? r : -r, rz = iz < 0.0 ? r : -r;
+        cand = bbox_hits_nf(ix, iy, iz, o, g0.x + rx, g0.x - rx, g0.y + ry, g0.y - ry, g1.x + rz, g1.x - rz);
+    }
+    if (cand) { bestF = a; w.best = prim; w.bestLen = t; }
 }
 // UnboundedObjects, in array order, accepted only when Float.compare a bestFloat = Less (Scene.fs:77-86)
 template <bool LDS, bool COUNT>

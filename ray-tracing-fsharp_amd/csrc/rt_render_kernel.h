@@ -25,6 +25,9 @@ namespace rtd {
 #define RTD_MAX_CHUNK 64
 #define RTD_MAX_PARK 256
 #define RTD_PARK_DEFAULT 64
+#ifndef RTD_PARK_L_DEFAULT
+#define RTD_PARK_L_DEFAULT 64 /* entries of a wave's pool of parked Lambert hits; 0: Lambert hits are shaded where they fall */
+#endif
 
 struct RenderParams {
     const CameraParams *cam_ptr;   // device copy of the camera: read where a camera ray is built, not held in SGPRs
@@ -44,13 +47,14 @@ struct RenderParams {
     int32_t yield_lanes;           // see Sched: a stage yields once this many lanes wait for another stage
     int32_t refill_lanes;          // see Sched: idle lanes are refilled once this many are idle
     int32_t park;                  // entries of a wave's park pool (0: rare styles are shaded in place)
+    int32_t park_l;                // entries of a wave's pool of parked LAMBERT hits (0: they are shaded where they fall)
     int32_t *accum;                // [n_rows*cols][4]
     uint8_t *rgb;                  // [n_rows*cols][3] or null
     unsigned long long *counters;  // [16]: rays, aabb, prim, refl, samples, pixels_early, -, -, then stage executions (COUNT):
                                    //       [8] refill [9] node trips [10] leaf stages [11] shade stages [12] lanes refilled [13] lanes shaded
                                    //       and, 160 bytes in, [0] slow stages [1] lanes in them [2] lanes parked
     unsigned int *queue;           // work-unit counter of the fused kernel / of pass A, zeroed before launch
-    unsigned char *park_pool;      // [waves of the grid][RTD_PARK_ENTRY_BYTES * park]: per-wave pools of parked paths (see Sched)
+    unsigned char *park_pool;      // [waves of the grid][RTD_PARK_ENTRY_BYTES * (park + park_l)]: per-wave pools of parked paths (see Sched)
     // two-pass rendering (see render_kernel): pass A appends (cost << 32 | local pixel) for every pixel that continues;
     // pass B walks `live_list` (those pixels ordered by decreasing cost) with its own queue
     unsigned long long *pairs;
@@ -130,6 +134,12 @@ struct StageStats { // wave-uniform, COUNT variant only
     unsigned long long tRefill, tSlow, tWalk, tShade; // shader-clock cycles this wave spent inside each stage (s_memtime)
 };
 
+// Diagnostic builds (-DRTD_STAGE_CLOCKS): the per-stage cycle sums of the counting variant in the timed variant too
+#ifdef RTD_STAGE_CLOCKS
+#define RTD_CLK true
+#else
+#define RTD_CLK false
+#endif
 #define RTD_YIELD_DEFAULT 44
 #define RTD_REFILL_DEFAULT 16
 
@@ -150,7 +160,7 @@ struct StageStats { // wave-uniform, COUNT variant only
 // (or switched off, p.park = 0) leaves the path in its lane and the general code runs for it at the next turn of the loop.
 // Which lane computes what when has no effect on any result: streams are per item.
 #define RTD_PARK_ENTRY_BYTES 96 /* 5 x 16 B + 8 B, padded */
-enum { L_IDLE = 0, L_WALK = 1, L_DONE = 2, L_SLOW = 3 };
+enum { L_IDLE = 0, L_WALK = 1, L_DONE = 2, L_SLOW = 3, L_LAMB = 4 };
 
 template <bool LDS, bool COUNT, bool TEX>
 struct Sched {
@@ -158,8 +168,9 @@ struct Sched {
     const SceneView<LDS> &sc;
     Counters &cnt;
     StageStats &ss;
-    unsigned char *pool; // this wave's park pool
-    uint32_t parked;     // wave-uniform
+    unsigned char *pool; // this wave's park pools: the general one, then the Lambert one
+    uint32_t parked;     // entries in the general pool (wave-uniform)
+    uint32_t parkedL;    // entries in the Lambert pool (wave-uniform)
     const int end;
     // lane state
     int st;
@@ -174,7 +185,7 @@ struct Sched {
     uint32_t result;
 
     RTD_INLINE Sched(const RenderParams &p_, const SceneView<LDS> &sc_, Counters &cnt_, StageStats &ss_, unsigned char *pool_)
-        : p(p_), sc(sc_), cnt(cnt_), ss(ss_), pool(pool_), parked(0u), end(sc_.end) {
+        : p(p_), sc(sc_), cnt(cnt_), ss(ss_), pool(pool_), parked(0u), parkedL(0u), end(sc_.end) {
         st = L_IDLE;
         o = mk(0, 0, 0); d = mk(0, 0, 0);
         walk_begin(w, sc.first); w.off = end; // idle lanes are parked at `end`
@@ -212,40 +223,46 @@ struct Sched {
         return false; // Scene.fs:144's ValueOption.get would throw; the sample counts as Black (adds nothing)
     }
 
-    // ---- park pool: entry e of field f sits at pool + (f * park + e) * 16 (fields 0-4) / pool + 80 * park + e * 8 (field 5) ----
-    RTD_INLINE void park_store(uint32_t e) {
-        d2 *f = (d2 *) pool;
-        const uint32_t K = (uint32_t) p.park;
+    // ---- park pools: entry e of field f sits at base + (f * K + e) * 16 (fields 0-4) / base + 80 * K + e * 8 (field 5), K = the pool's capacity ----
+    RTD_INLINE void park_store(unsigned char *base, uint32_t K, uint32_t e) {
+        d2 *f = (d2 *) base;
         d2 v;
         v.x = o.x; v.y = o.y; f[e] = v;
         v.x = o.z; v.y = d.x; f[K + e] = v;
         v.x = d.y; v.y = d.z; f[2u * K + e] = v;
         i4 r; r.x = __double2loint(w.bestLen); r.y = __double2hiint(w.bestLen); r.z = (int) colour; r.w = (int) slotOff;
-        ((i4 *) pool)[3u * K + e] = r;
+        ((i4 *) base)[3u * K + e] = r;
         r.x = (int) rng.x; r.y = (int) rng.y; r.z = (int) rng.z; r.w = (int) rng.w;
-        ((i4 *) pool)[4u * K + e] = r;
+        ((i4 *) base)[4u * K + e] = r;
         i2 b; b.x = bounces; b.y = w.best;
-        ((i2 *) (pool + 80u * K))[e] = b;
+        ((i2 *) (base + 80u * K))[e] = b;
     }
-    RTD_INLINE void park_load(uint32_t e) {
-        const d2 *f = (const d2 *) pool;
-        const uint32_t K = (uint32_t) p.park;
+    RTD_INLINE void park_load(const unsigned char *base, uint32_t K, uint32_t e, int state) {
+        const d2 *f = (const d2 *) base;
         const d2 a = f[e], b = f[K + e], c = f[2u * K + e];
-        const i4 t = ((const i4 *) pool)[3u * K + e], r = ((const i4 *) pool)[4u * K + e];
-        const i2 bo = ((const i2 *) (pool + 80u * K))[e];
+        const i4 t = ((const i4 *) base)[3u * K + e], r = ((const i4 *) base)[4u * K + e];
+        const i2 bo = ((const i2 *) (base + 80u * K))[e];
         o = mk(a.x, a.y, b.x); d = mk(b.y, c.x, c.y);
         w.bestLen = __hiloint2double(t.y, t.x); colour = (uint32_t) t.z; slotOff = (uint32_t) t.w;
         rng.x = (uint32_t) r.x; rng.y = (uint32_t) r.y; rng.z = (uint32_t) r.z; rng.w = (uint32_t) r.w;
         bounces = bo.x; w.best = bo.y;
         w.off = end;
-        st = L_SLOW;
+        st = state;
     }
-    // How many of `nIdle` idle lanes take parked paths now (wave-uniform): all of them once the pool holds that many, and
-    // whatever is left when there are no new items.
-    RTD_INLINE uint32_t unpark_count(uint32_t nIdle, bool haveNew) const {
-        if (parked == 0u) return 0u;
-        if (parked >= nIdle) return nIdle;
-        return haveNew ? 0u : parked;
+    RTD_INLINE unsigned char *pool_l() const { return pool + (size_t) RTD_PARK_ENTRY_BYTES * (size_t) p.park; }
+    // How the `nIdle` idle lanes of a refill are served (wave-uniform): a FULL batch of parked Lambert hits if that pool holds one,
+    // else a full batch of parked general hits, else new items; once there are no new items, whatever the pools still hold.
+    RTD_INLINE void unpark_plan(uint32_t nIdle, bool haveNew, uint32_t &nUnL, uint32_t &nUnA) const {
+        nUnL = nUnA = 0u;
+        if (parkedL >= nIdle) nUnL = nIdle;
+        else if (parked >= nIdle) nUnA = nIdle;
+        else if (!haveNew) { nUnL = parkedL; nUnA = parked < nIdle - nUnL ? parked : nIdle - nUnL; }
+    }
+    // the idle lane of rank `rank` takes its parked path, if the plan gives it one
+    RTD_INLINE bool unpark_lane(uint32_t rank, uint32_t nUnL, uint32_t nUnA) {
+        if (rank < nUnL) { park_load(pool_l(), (uint32_t) p.park_l, parkedL - 1u - rank, L_LAMB); return true; }
+        if (rank < nUnL + nUnA) { park_load(pool, (uint32_t) p.park, parked - 1u - (rank - nUnL), L_SLOW); return true; }
+        return false;
     }
 
     // what follows Hittable.Reflection in Scene.traceRay (Scene.fs:105-112)
@@ -268,10 +285,19 @@ struct Sched {
     RTD_INLINE void stage_slow() {
         const unsigned long long m = __builtin_amdgcn_ballot_w64(st == L_SLOW);
         if (m == 0ull) return;
-        if (COUNT) { ss.slow++; ss.slowLanes += (uint32_t) __popcll(m); }
+        if (COUNT || RTD_CLK) { ss.slow++; ss.slowLanes += (uint32_t) __popcll(m); }
         if (st == L_SLOW) {
             const V3 strike = walk(o, d, w.bestLen); // Ray.walkAlong ray bestLength (Scene.fs:91)
             after_reflection(reflection<LDS, TEX>(sc, w.best, strike, o, d, colour, rng));
+        }
+    }
+
+    // ---- lamb: the Lambert bounce (Sphere.fs:202-222) for the lanes that took parked Lambert hits (or whose hit found the pool full) ----
+    RTD_INLINE void stage_lamb() {
+        if (__builtin_amdgcn_ballot_w64(st == L_LAMB) == 0ull) return;
+        if (st == L_LAMB) {
+            const V3 strike = walk(o, d, w.bestLen); // Ray.walkAlong ray bestLength (Scene.fs:91)
+            after_reflection(reflection_fast<LDS>(sc, w.best, sc.meta[w.best], strike, o, d, colour, rng));
         }
     }
 
@@ -281,16 +307,19 @@ struct Sched {
     RTD_INLINE void stage_walk() {
         if (__builtin_amdgcn_ballot_w64(st == L_WALK) == 0ull) return;
         const int nBusy = __popcll(__builtin_amdgcn_ballot_w64(st != L_IDLE));
-        WalkCtx c = walk_ctx(d, w); // cheap to re-derive; keeps 9 doubles out of the parked state
         const int stop = (nBusy - p.yield_lanes) > 0 ? (nBusy - p.yield_lanes) : 0; // active <= stop  <=>  waiting >= yield
         if constexpr (LDS && !COUNT) {
             // the timed variant: the hand-written single-precision filter loop with its queue of pending leaves (rt_device.h); the
             // leaf pass makes the leaf's exact box test and then the sphere's; a lane is finished when its walk is exhausted AND
             // its queue is empty
             const WalkCtx32 f = walk_ctx32(o, d, p.off.bmax);
+            double bestF = (w.best < 0) ? __builtin_inf() : w.bestLen * w.bestLen; // `a = point * point` (Scene.fs:45), recomputed
+            const bool implied = p.off.box_implied != 0; // (rays of this kernel are unitised: Ray.make')
+            if (RTD_CLK) ss.trips++; // (diagnostic build: walk-stage entries and leaf passes; the loop's trips are not counted)
             for (;;) {
                 w.off = node_loop_lds32(w.off, pend, end, stop, f);
-                if (pend != 0u) leaf_test_object_exact<LDS>(sc, o, d, c, w, pend_pop(pend));
+                if (RTD_CLK && __builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) ss.leaf++;
+                if (pend != 0u) leaf_test_object_exact<LDS>(sc, o, d, bestF, w, pend_pop(pend), implied);
                 const bool fin = (st == L_WALK) && (w.off >= end) && pend == 0u;
                 if (fin) st = L_DONE;
                 const int nWalk = __popcll(__builtin_amdgcn_ballot_w64(st == L_WALK));
@@ -299,6 +328,7 @@ struct Sched {
             }
             return;
         }
+        WalkCtx c = walk_ctx(d, w); // cheap to re-derive; keeps 9 doubles out of the parked state
         for (;;) {
             for (;;) {
                 const bool act = w.off < end;
@@ -327,7 +357,7 @@ struct Sched {
     RTD_INLINE void stage_shade() {
         const unsigned long long dm = __builtin_amdgcn_ballot_w64(st == L_DONE);
         if (dm == 0ull) return;
-        if (COUNT) { ss.shade++; ss.shadeLanes += (uint32_t) __popcll(dm); }
+        if (COUNT || RTD_CLK) { ss.shade++; ss.shadeLanes += (uint32_t) __popcll(dm); }
         if (st == L_DONE) {
             unbounded_tests<LDS, COUNT>(sc, o, d, w, cnt);
             if (w.best < 0) { ended = true; result = RTD_BLACK; st = L_IDLE; w.off = end; } // "never heard from again": Black (Scene.fs:102-104)
@@ -335,8 +365,11 @@ struct Sched {
                 if (COUNT) cnt.refl++;
                 const i2 m = sc.meta[w.best];
                 if (fast_style(m)) {
-                    const V3 strike = walk(o, d, w.bestLen); // Ray.walkAlong ray bestLength (Scene.fs:91)
-                    after_reflection(reflection_fast<LDS>(sc, w.best, m, strike, o, d, colour, rng));
+                    if (p.park_l > 0 && (((uint32_t) m.x >> 2) & 7u) != 0u) st = L_LAMB; // an untextured Lambert sphere: parked, bounced in full batches
+                    else {
+                        const V3 strike = walk(o, d, w.bestLen); // Ray.walkAlong ray bestLength (Scene.fs:91)
+                        after_reflection(reflection_fast<LDS>(sc, w.best, m, strike, o, d, colour, rng));
+                    }
                 } else st = L_SLOW;
             }
         }
@@ -345,10 +378,19 @@ struct Sched {
             if (sm != 0ull) {
                 const uint32_t room = (uint32_t) p.park - parked, want = (uint32_t) __popcll(sm);
                 const uint32_t rank = lane_rank(sm);
-                if (st == L_SLOW && rank < room) { park_store(parked + rank); st = L_IDLE; w.off = end; }
+                if (st == L_SLOW && rank < room) { park_store(pool, (uint32_t) p.park, parked + rank); st = L_IDLE; w.off = end; }
                 const uint32_t n = want < room ? want : room;
                 parked += n;
-                if (COUNT) ss.parkedLanes += n;
+                if (COUNT || RTD_CLK) ss.parkedLanes += n;
+            }
+        }
+        if (p.park_l > 0) {
+            const unsigned long long lm = __builtin_amdgcn_ballot_w64(st == L_LAMB);
+            if (lm != 0ull) {
+                const uint32_t room = (uint32_t) p.park_l - parkedL, want = (uint32_t) __popcll(lm);
+                const uint32_t rank = lane_rank(lm);
+                if (st == L_LAMB && rank < room) { park_store(pool_l(), (uint32_t) p.park_l, parkedL + rank); st = L_IDLE; w.off = end; }
+                parkedL += want < room ? want : room;
             }
         }
     }
@@ -375,18 +417,19 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsig
     const float perRcp = 1.0f / (float) per;
     for (;;) {
         L.ended = false;
-        const unsigned long long t0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long t0 = (COUNT || RTD_CLK) ? __builtin_amdgcn_s_memtime() : 0ull;
         // ---- refill: idle lanes take parked paths or the next items of the unit ----
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(L.st == L_IDLE);
         const bool haveNew = next < total;
-        if (idle != 0ull && (haveNew || L.parked != 0u) && (__popcll(idle) >= p.refill_lanes || ~idle == 0ull)) {
+        if (idle != 0ull && (haveNew || (L.parked | L.parkedL) != 0u) && (__popcll(idle) >= p.refill_lanes || ~idle == 0ull)) {
             const uint32_t nIdle = (uint32_t) __popcll(idle);
             const uint32_t rank = lane_rank(idle);
-            const uint32_t nUn = L.unpark_count(nIdle, haveNew);
-            if (COUNT) { ss.refill++; ss.refillLanes += nIdle; }
+            uint32_t nUnL, nUnA;
+            L.unpark_plan(nIdle, haveNew, nUnL, nUnA);
+            const uint32_t nUn = nUnL + nUnA;
+            if (COUNT || RTD_CLK) { ss.refill++; ss.refillLanes += nIdle; }
             if (L.st == L_IDLE) {
-                if (rank < nUn) L.park_load(L.parked - 1u - rank);
-                else {
+                if (!L.unpark_lane(rank, nUnL, nUnA)) {
                     const uint32_t item = next + (rank - nUn);
                     if (item < total) {
                         uint32_t j = fastDiv ? div_uniform(item, per, perRcp) : item / per;
@@ -399,21 +442,23 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsig
                     }
                 }
             }
-            L.parked -= nUn;
+            L.parked -= nUnA;
+            L.parkedL -= nUnL;
             next += nIdle - nUn;
             next = __builtin_amdgcn_readfirstlane(next);
         }
         if (__builtin_amdgcn_ballot_w64(L.st != L_IDLE) == 0ull) {
-            if (next >= total && L.parked == 0u) break;
+            if (next >= total && (L.parked | L.parkedL) == 0u) break;
             continue;
         }
-        const unsigned long long t1 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long t1 = (COUNT || RTD_CLK) ? __builtin_amdgcn_s_memtime() : 0ull;
         L.stage_slow();
-        const unsigned long long t2 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
+        L.stage_lamb();
+        const unsigned long long t2 = (COUNT || RTD_CLK) ? __builtin_amdgcn_s_memtime() : 0ull;
         L.stage_walk();
-        const unsigned long long t3 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long t3 = (COUNT || RTD_CLK) ? __builtin_amdgcn_s_memtime() : 0ull;
         L.stage_shade();
-        if (COUNT) { const unsigned long long t4 = __builtin_amdgcn_s_memtime(); ss.tRefill += t1 - t0; ss.tSlow += t2 - t1; ss.tWalk += t3 - t2; ss.tShade += t4 - t3; }
+        if (COUNT || RTD_CLK) { const unsigned long long t4 = __builtin_amdgcn_s_memtime(); ss.tRefill += t1 - t0; ss.tSlow += t2 - t1; ss.tWalk += t3 - t2; ss.tShade += t4 - t3; }
         if (L.ended) {
             L.add_result(acc + (L.slotOff & 0xFFFFu));
             if (COST) lds_add(acc + 10u * (uint32_t) p.chunk + (L.slotOff >> 16), (uint32_t) L.bounces + 1u); // ~ Scene.hitObject calls of this path
@@ -466,7 +511,7 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
 
     for (;;) {
         L.ended = false;
-        const unsigned long long t0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long t0 = (COUNT || RTD_CLK) ? __builtin_amdgcn_s_memtime() : 0ull;
         // ---- ranges: flush what has drained, reserve the next one when the current one has no items left ----
         if (prevNpx != 0u && prevOut == 0u) { flush(prevFirst, prevNpx, prevSlot); prevNpx = 0u; }
         if (curNext >= curTotal && prevNpx == 0u) {
@@ -519,16 +564,17 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
         {
             const uint32_t nIdle = (uint32_t) __popcll(idle);
             const uint32_t avail = curTotal - curNext;
-            if (nIdle != 0u && (avail != 0u || L.parked != 0u) && ((int) nIdle >= p.refill_lanes || nIdle == 64u)) {
+            if (nIdle != 0u && (avail != 0u || (L.parked | L.parkedL) != 0u) && ((int) nIdle >= p.refill_lanes || nIdle == 64u)) {
                 const uint32_t rank = lane_rank(idle);
-                const uint32_t nUn = L.unpark_count(nIdle, avail != 0u);
-                if (COUNT) { ss.refill++; ss.refillLanes += nIdle; }
+                uint32_t nUnL, nUnA;
+                L.unpark_plan(nIdle, avail != 0u, nUnL, nUnA);
+                const uint32_t nUn = nUnL + nUnA;
+                if (COUNT || RTD_CLK) { ss.refill++; ss.refillLanes += nIdle; }
                 const uint32_t rest = nIdle - nUn;
                 const uint32_t take = rest < avail ? rest : avail;
                 bool started = false;
                 if (L.st == L_IDLE) {
-                    if (rank < nUn) L.park_load(L.parked - 1u - rank);
-                    else if (rank - nUn < take) {
+                    if (!L.unpark_lane(rank, nUnL, nUnA) && rank - nUn < take) {
                         const uint32_t item = curNext + (rank - nUn);
                         const uint32_t j = fastDiv ? div_uniform(item, n2, perRcp) : item / n2;
                         const uint32_t smp = n1 + (item - j * n2);
@@ -538,20 +584,22 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
                         started = L.start_item(pkey, smp, row, col, curSlot * SW + j * 3u);
                     }
                 }
-                L.parked -= nUn;
+                L.parked -= nUnA;
+                L.parkedL -= nUnL;
                 curNext += take;
                 curOut += (uint32_t) __popcll(__builtin_amdgcn_ballot_w64(started));
             }
         }
         if (__builtin_amdgcn_ballot_w64(L.st != L_IDLE) == 0ull) continue;
 
-        const unsigned long long t1 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long t1 = (COUNT || RTD_CLK) ? __builtin_amdgcn_s_memtime() : 0ull;
         L.stage_slow();
-        const unsigned long long t2 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
+        L.stage_lamb();
+        const unsigned long long t2 = (COUNT || RTD_CLK) ? __builtin_amdgcn_s_memtime() : 0ull;
         L.stage_walk();
-        const unsigned long long t3 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long t3 = (COUNT || RTD_CLK) ? __builtin_amdgcn_s_memtime() : 0ull;
         L.stage_shade();
-        if (COUNT) { const unsigned long long t4 = __builtin_amdgcn_s_memtime(); ss.tRefill += t1 - t0; ss.tSlow += t2 - t1; ss.tWalk += t3 - t2; ss.tShade += t4 - t3; }
+        if (COUNT || RTD_CLK) { const unsigned long long t4 = __builtin_amdgcn_s_memtime(); ss.tRefill += t1 - t0; ss.tSlow += t2 - t1; ss.tWalk += t3 - t2; ss.tShade += t4 - t3; }
         if (L.ended) L.add_result(wv + L.slotOff);
         const bool inCur = (curNpx != 0u) && ((L.slotOff >= SW) == (curSlot == 1u));
         curOut -= (uint32_t) __popcll(__builtin_amdgcn_ballot_w64(L.ended && inCur));
@@ -613,7 +661,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     RTD_AS3 uint32_t *acc = wv;
     RTD_AS3 uint32_t *pix = wv + 6u * P;
     RTD_AS3 uint32_t *live = pix + 4u * P;
-    unsigned char *pool = p.park_pool + ((size_t) blockIdx.x * (BLOCK / 64) + (size_t) wave) * (size_t) RTD_PARK_ENTRY_BYTES * (size_t) p.park;
+    unsigned char *pool = p.park_pool + ((size_t) blockIdx.x * (BLOCK / 64) + (size_t) wave) * (size_t) RTD_PARK_ENTRY_BYTES * (size_t) (p.park + p.park_l);
 
     const uint64_t nLocal = (uint64_t) p.n_rows * (uint64_t) p.cols;
     const uint32_t k = (uint32_t) p.k;
@@ -724,24 +772,26 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
             atomicAdd(&p.counters[1], (unsigned long long) b);
             atomicAdd(&p.counters[2], (unsigned long long) c);
             atomicAdd(&p.counters[3], (unsigned long long) dd);
-            atomicAdd(&p.counters[8], (unsigned long long) ss.refill);
-            atomicAdd(&p.counters[9], (unsigned long long) ss.trips);
-            atomicAdd(&p.counters[10], (unsigned long long) ss.leaf);
-            atomicAdd(&p.counters[11], (unsigned long long) ss.shade);
-            atomicAdd(&p.counters[12], (unsigned long long) ss.refillLanes);
-            atomicAdd(&p.counters[13], (unsigned long long) ss.shadeLanes);
-            atomicAdd(&p.counters[20], (unsigned long long) ss.slow);
-            atomicAdd(&p.counters[21], (unsigned long long) ss.slowLanes);
-            atomicAdd(&p.counters[22], (unsigned long long) ss.parkedLanes);
-            atomicAdd(&p.counters[23], ss.tRefill);
-            atomicAdd(&p.counters[24], ss.tSlow);
-            atomicAdd(&p.counters[25], ss.tWalk);
-            atomicAdd(&p.counters[26], ss.tShade);
             const unsigned long long tEnd = __builtin_amdgcn_s_memrealtime();
             atomicAdd(&p.counters[14], tEnd - tStart);                         // sum of wave lifetimes
             atomicMax(&p.counters[15], tEnd);                                  // last wave to finish
             atomicMax(&p.counters[7], 0x4000000000000000ull - tStart);         // (2^62 - earliest start)
         }
+    }
+    if ((COUNT || RTD_CLK) && lane == 0) {
+        atomicAdd(&p.counters[8], (unsigned long long) ss.refill);
+        atomicAdd(&p.counters[9], (unsigned long long) ss.trips);
+        atomicAdd(&p.counters[10], (unsigned long long) ss.leaf);
+        atomicAdd(&p.counters[11], (unsigned long long) ss.shade);
+        atomicAdd(&p.counters[12], (unsigned long long) ss.refillLanes);
+        atomicAdd(&p.counters[13], (unsigned long long) ss.shadeLanes);
+        atomicAdd(&p.counters[20], (unsigned long long) ss.slow);
+        atomicAdd(&p.counters[21], (unsigned long long) ss.slowLanes);
+        atomicAdd(&p.counters[22], (unsigned long long) ss.parkedLanes);
+        atomicAdd(&p.counters[23], ss.tRefill);
+        atomicAdd(&p.counters[24], ss.tSlow);
+        atomicAdd(&p.counters[25], ss.tWalk);
+        atomicAdd(&p.counters[26], ss.tShade);
     }
     if (lane == 0) {
         atomicAdd(&p.counters[4], (unsigned long long) s);

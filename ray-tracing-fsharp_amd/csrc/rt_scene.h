@@ -527,6 +527,16 @@ static void encode_image(HostScene &s) {
         lk32[3] = leaf ? 16 : 0;
     }
     off.bmax = bmax;
+    {   // the hypotheses of leaf_test_object_exact's claim (rt_device.h): the exact leaf-box test is then implied by a sphere hit
+        double rmax = 0.0;
+        bool ok = std::isfinite(bmax) && bmax <= 1000.0f;
+        for (size_t j = 0; j < nb; ++j) {
+            const double r = h[(size_t) s.objToOrig[j]].radius;
+            if (!(r > 0.0 && r <= 100.0)) ok = false;
+            if (r > rmax) rmax = r;
+        }
+        off.box_implied = (ok && rmax * (double) bmax <= 500.0) ? 1 : 0;
+    }
     for (size_t j = 0; j < nobj; ++j) {
         const rt_hittable &o = h[(size_t) s.objToOrig[j]];
         double *g = pgeo + j * 6;

@@ -230,7 +230,7 @@ size_t rt_abi_offsetof(int which, int field) {
                     F(rt_camera, focal_length), F(rt_camera, samples_per_pixel), F(rt_camera, bounce_depth))
     case 3: RT_OFFS(rt_scene_info, F(rt_scene_info, n_bounded), F(rt_scene_info, n_unbounded), F(rt_scene_info, n_nodes), F(rt_scene_info, tree_depth),
                     F(rt_scene_info, n_textures), F(rt_scene_info, lds_resident), F(rt_scene_info, walk_tree), F(rt_scene_info, walk_tree_depth),
-                    F(rt_scene_info, scene_bytes), F(rt_scene_info, texel_bytes), F(rt_scene_info, walk_tree_nodes), F(rt_scene_info, reserved))
+                    F(rt_scene_info, scene_bytes), F(rt_scene_info, texel_bytes), F(rt_scene_info, walk_tree_nodes), F(rt_scene_info, leaf_box_implied))
     case 4: RT_OFFS(rt_stats, F(rt_stats, rays), F(rt_stats, aabb_tests), F(rt_stats, prim_tests), F(rt_stats, reflections), F(rt_stats, samples),
                     F(rt_stats, pixels), F(rt_stats, pixels_early), F(rt_stats, kernel_ms), F(rt_stats, total_ms))
     case 5: RT_OFFS(rt_render_options, F(rt_render_options, struct_size), F(rt_render_options, block_threads), F(rt_render_options, chunk_pixels),
@@ -331,7 +331,7 @@ int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
     out->n_unbounded = h.off.n_unbounded;
     out->n_nodes = (int32_t) h.tree.skip.size();
     out->walk_tree_nodes = h.off.n_nodes;
-    out->reserved = 0;
+    out->leaf_box_implied = h.off.box_implied;
     out->tree_depth = h.tree.depth;
     out->walk_tree = h.walkKind;
     out->walk_tree_depth = h.walkTree.depth;
@@ -452,6 +452,7 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
     p.k = half < 5 ? half : 5; // min 5 (spp / 2), Scene.fs:172
     p.chunk = chunk;
     p.park = plan.park;
+    p.park_l = plan.park > 0 ? RTD_PARK_L_DEFAULT : 0; // the Lambert pool rides with the general one ("never park" switches both off)
     p.yield_lanes = set.yield ? set.yield : RTD_YIELD_DEFAULT;
     p.refill_lanes = set.refill ? set.refill : RTD_REFILL_DEFAULT;
     p.accum = (int32_t *) d_accum;
@@ -487,7 +488,7 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
     // launch that uses them, so no launch shares state with another and the call returns without waiting for the device.
     const size_t pairsBytes = twoPass ? (((size_t) nLocal * 8u + 15u) & ~(size_t) 15u) : 0u, listBytes = twoPass ? (((size_t) nLocal * 4u + 15u) & ~(size_t) 15u) : 0u;
     const size_t sortBytes = twoPass ? (3u * RTD_COST_BUCKETS * 4u + 15u) & ~(size_t) 15u : 0u;
-    const size_t poolBytes = (size_t) (twoPass ? fullGrid : grid) * (size_t) wavesPerBlock * (size_t) RTD_PARK_ENTRY_BYTES * (size_t) plan.park;
+    const size_t poolBytes = (size_t) (twoPass ? fullGrid : grid) * (size_t) wavesPerBlock * (size_t) RTD_PARK_ENTRY_BYTES * (size_t) (p.park + p.park_l);
     unsigned char *scr = nullptr;
     if (grid > 0 || stats) HIP_TRY(hipMallocAsync((void **) &scr, RT_SCRATCH_BYTES + pairsBytes + listBytes + sortBytes + poolBytes, st));
     Pending &cl = pd; // on every exit path its destructor (or collect_stats) gives the scratch back
@@ -1138,13 +1139,17 @@ __global__ void __launch_bounds__(1024) k_hit_object_lds(const RenderParams p, i
     Walk w;
     walk_begin(w, sc.first);
     if (!valid) w.off = sc.end;
-    WalkCtx c = walk_ctx(d, w);
     const WalkCtx32 f = walk_ctx32(o, d, p.off.bmax);
+    double bestF = __builtin_inf();
+    // the claim that lets the leaf pass skip the exact box test needs unit directions: this hook's rays are arbitrary, so it holds
+    // a lane to the claim only when its direction is one (|d|^2 within 1e-15 of 1, as Ray.make' leaves it)
+    const double n2 = dot(d, d);
+    const bool implied = p.off.box_implied != 0 && n2 >= 1.0 - 1e-15 && n2 <= 1.0 + 1e-15;
     uint32_t pend = 0u;
     for (;;) {
         w.off = node_loop_lds32(w.off, pend, sc.end, 0, f); // until no lane of the wave can step: walks exhausted or queues full
         if (__builtin_amdgcn_ballot_w64(pend != 0u) == 0ull) break;
-        if (pend != 0u) leaf_test_object_exact<true>(sc, o, d, c, w, pend_pop(pend));
+        if (pend != 0u) leaf_test_object_exact<true>(sc, o, d, bestF, w, pend_pop(pend), implied);
     }
     Counters cnt; cnt.rays = cnt.aabb = cnt.prim = cnt.refl = 0;
     unbounded_tests<true, false>(sc, o, d, w, cnt);

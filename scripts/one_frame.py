@@ -23,6 +23,7 @@ ap.add_argument("--passes", type=int, default=0)
 ap.add_argument("--yield-lanes", type=int, default=0)
 ap.add_argument("--refill-lanes", type=int, default=0)
 ap.add_argument("--no-tune", action="store_true", help="skip rt_scene_tune")
+ap.add_argument("--stage-stats", action="store_true", help="print rt_last_stage_stats of a timed launch too (a -DRTD_STAGE_CLOCKS build fills the cycle sums)")
 a = ap.parse_args()
 rt.set_launch_config(a.block, a.chunk)
 rt.set_park(a.park)
@@ -37,7 +38,7 @@ local = torch.zeros((rows, cols, 4), dtype=torch.int32, device="cuda:0")
 for _ in range(a.launches):
     st = rtd.render_shard_device(scene, cam, w, h, 2024, 0, 0, 1, rows, local, counters=a.counters, want_stats=True)
     print({k: st[k] for k in ("kernel_ms", "rays", "aabb_tests", "prim_tests", "samples")}, flush=True)
-    if a.counters:
+    if a.counters or a.stage_stats:
         import ctypes
         ss = (ctypes.c_uint64 * 16)()
         rt.lib.rt_last_stage_stats(ss)

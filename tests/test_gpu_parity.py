@@ -225,6 +225,85 @@ def test_hit_object_through_the_hand_written_node_loop(rt, orc):
         assert 0.05 < np.mean(h2 >= 0) <= 1.0
 
 
+def test_leaf_box_is_implied_by_the_sphere_hit(rt, orc):
+    """The timed variant's leaf pass does not evaluate a Leaf's own BoundingBox.hits (Scene.fs:41) when Sphere.firstIntersection has
+    found a hit from its Greater branch in a scene of moderate extent -- the claim proved above leaf_test_object_exact in
+    csrc/rt_device.h.  Rays aimed where the claim is thinnest: tangent to a sphere AT one of the six points where it touches its box
+    (offsets from 1 ulp to 1e-7 either way, so the discriminant crosses the 1e-8 band and the ray crosses the box face), origins
+    inside a sphere a few ulps to 1e-6 under a pole and leaving at shallow angles, origins ON the surface (what every bounce
+    produces), at the poles too.  Three scenes: one inside the claim's bounds with small spheres spread over +-300, the final scene's
+    own scale, and one outside the bounds (radii 20 to 60), where the box test is evaluated for every candidate.  The device's two
+    routes and the oracle must name the same object and the same strike point for every ray."""
+    P, S, H, Px, Tex = scenes.P, scenes.S, scenes.H, scenes.Px, scenes.Tex
+    rng = np.random.default_rng(4242)
+
+    def scene_of(n, spread, rlo, rhi):
+        objs, placed = [], []
+        while len(objs) < n:
+            c = rng.uniform(-spread, spread, 3)
+            r = float(np.exp(rng.uniform(np.log(rlo), np.log(rhi))))
+            if all(np.linalg.norm(c - c2) > r + r2 + 0.01 for c2, r2 in placed):
+                placed.append((c, r))
+                style = [S.LambertReflection(0.5, Tex(Px(200, 100, 50))), S.Glass(1.0, Tex(Px(255, 255, 255)), 1.5), S.PureReflection(0.9, Tex(Px(180, 180, 180)))][len(objs) % 3]
+                objs.append(H.Sphere(rt.Sphere.make(style, P(*c), r)))
+        objs.append(H.UnboundedSphere(rt.Sphere.make(S.LightSource(Tex(Px(255, 255, 255))), P(0.0, 0.0, 0.0), 5000.0)))
+        return objs, placed
+
+    for n_sph, spread, rlo, rhi, expect in ((60, 300.0, 0.05, 1.0, 1), (60, 11.0, 0.2, 1.0, 1), (12, 150.0, 20.0, 60.0, 0)):
+        objs, placed = scene_of(n_sph, spread, rlo, rhi)
+        s, o = _scene_pair(rt, orc, objs)
+        info = s.info()
+        assert info["lds_resident"] == 1 and info["leaf_box_implied"] == expect
+        n = 240_000
+        which = rng.integers(0, len(placed), n)
+        c = np.array([placed[i][0] for i in which])
+        r = np.array([placed[i][1] for i in which])
+        axis = rng.integers(0, 3, n)
+        sign = rng.choice([-1.0, 1.0], n)
+        e = np.eye(3)[axis] * sign[:, None]                       # the pole's outward normal
+        pole = c + e * r[:, None]
+        tang = rng.normal(size=(n, 3))
+        tang -= np.sum(tang * e, axis=1, keepdims=True) * e       # a direction in the box face's plane
+        tang /= np.linalg.norm(tang, axis=1, keepdims=True)
+        mag = np.exp(rng.uniform(np.log(1e-16), np.log(1e-6), n)) * rng.choice([-1.0, 1.0, 0.0], n, p=[0.45, 0.45, 0.1])
+        rays = np.zeros((n, 6))
+        k = n // 4
+        # (1) tangent at a pole, shifted along the normal by +-mag * r, started 0.1..30 away
+        aim = pole + e * (mag * r)[:, None]
+        dist = rng.uniform(0.1, 30.0, n)
+        rays[:, :3] = aim - tang * dist[:, None]
+        rays[:, 3:] = tang
+        # (2) origin inside, just under a pole, leaving at a shallow angle through (or beside) the pole region
+        sl = slice(k, 2 * k)
+        depth = np.exp(rng.uniform(np.log(1e-16), np.log(1e-6), n))
+        tilt = np.exp(rng.uniform(np.log(1e-9), np.log(1e-2), n)) * rng.choice([-1.0, 1.0], n)
+        d2 = tang + e * tilt[:, None]
+        d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+        rays[sl, :3] = (pole - e * (depth * r)[:, None])[sl]
+        rays[sl, 3:] = d2[sl]
+        # (3) origin ON the surface at a random point (and at a pole for a third of them), any direction: self-hits at t ~ 0 and
+        #     true second hits through the sphere
+        sl = slice(2 * k, 3 * k)
+        q = rng.normal(size=(n, 3)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+        q = np.where((rng.random(n) < 0.33)[:, None], e, q)
+        rays[sl, :3] = (c + q * r[:, None])[sl]
+        dd = rng.normal(size=(n, 3)); dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+        rays[sl, 3:] = dd[sl]
+        # (4) tangent anywhere on the silhouette (not only at poles), offsets across the 1e-8 band
+        sl = slice(3 * k, n)
+        t2 = np.cross(q, dd); t2 /= np.linalg.norm(t2, axis=1, keepdims=True)
+        rays[sl, :3] = (c + q * (r * (1.0 + mag))[:, None] - t2 * dist[:, None])[sl]
+        rays[sl, 3:] = t2[sl]
+        rays[:, 3:] /= np.linalg.norm(rays[:, 3:], axis=1, keepdims=True)
+        h1, s1 = rt.hooks.hit_object_lds(s, rays)
+        h0, s0, _ = rt.hooks.hit_object(s, rays)
+        h2, s2, _ = o.hit_object(rays)
+        assert np.array_equal(h0, h2) and _same_f64(s0, s2)
+        assert np.array_equal(h1, h2) and _same_f64(s1, s2)
+        bounded = (h2 >= 0) & (h2 < n_sph)
+        assert 0.2 < np.mean(bounded) < 0.98  # the rays do hit, and do miss, the spheres they graze
+
+
 def test_leaf_queue_of_the_node_loop_under_pressure(rt, orc):
     """The timed variant's node loop queues hit Leaves (two 16-bit entries per lane) and stops a lane only when its queue is full.
     Rays that run through dozens of overlapping Leaf boxes -- a skewer of nested and overlapping spheres, exact duplicates among them
