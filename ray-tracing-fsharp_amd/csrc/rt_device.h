@@ -908,20 +908,25 @@ RTD_INLINE bool fast_style(i2 m) {
 #endif
     return (((uint32_t) m.y) >> 24) == 0u && (ks == (RTD_KIND_SPHERE | (0u << 2)) || ks == (RTD_KIND_SPHERE | (4u << 2)) || ks == (RTD_KIND_PLANE | (0u << 2)));
 }
+// The Lambert case in two pieces, so that the render kernel can park a Lambert hit between them as {strike, inside} instead of the
+// whole incoming ray: Sphere.reflection's prologue (Sphere.fs:162-182: is the ray's origin inside the sphere?) ...
 template <bool LDS>
-RTD_INLINE bool reflection_fast(const SceneView<LDS> &sc, int obj, i2 m, V3 strike, V3 &o, V3 &d, uint32_t &colour, Rng &rng) {
+RTD_INLINE bool lambert_inside(const SceneView<LDS> &sc, int obj, i2 m, V3 o) {
+    const d2 g0 = sc.geo[obj * 3 + 0], g1 = sc.geo[obj * 3 + 1];
+    const bool flipped = (m.x >> 5) & 1;
+    const V3 co = vsub(mk(g0.x, g0.y, g1.x), o);
+    const int cmp = fcmp(dot(co, co), g1.y); // Sphere.fs:165-179
+    return (cmp != CMP_GT) != flipped;
+}
+// ... and the bounce itself from the strike point (Sphere.normal Sphere.fs:65-66, LambertReflection Sphere.fs:202-222)
+template <bool LDS>
+RTD_INLINE void lambert_bounce(const SceneView<LDS> &sc, int obj, i2 m, V3 strike, bool inside, V3 &o, V3 &d, uint32_t &colour, Rng &rng) {
     const uint32_t texColour = (uint32_t) m.y & 0x00FFFFFFu;
-    if ((((uint32_t) m.x >> 2) & 7u) == 0u) { colour = pix_combine(colour, texColour); return true; } // LightSource, sphere or plane
     const d2 g0 = sc.geo[obj * 3 + 0], g1 = sc.geo[obj * 3 + 1];
     const double albedo = sc.geo[obj * 3 + 2].x;
-    const V3 c = mk(g0.x, g0.y, g1.x);
-    const double r2 = g1.y;
-    const bool flipped = (m.x >> 5) & 1;
     V3 n;
-    if (!unitise(vsub(strike, c), n)) n = mk(0.0, 0.0, 0.0); // Sphere.normal (Sphere.fs:65-66)
-    V3 co = vsub(c, o);
-    int cmp = fcmp(dot(co, co), r2); // Sphere.fs:165-179
-    if ((cmp != CMP_GT) != flipped) n = vscale(-1.0, n);
+    if (!unitise(vsub(strike, mk(g0.x, g0.y, g1.x)), n)) n = mk(0.0, 0.0, 0.0); // Sphere.normal (Sphere.fs:65-66)
+    if (inside) n = vscale(-1.0, n);
     colour = pix_darken(albedo, pix_combine(colour, texColour)); // Sphere.fs:203-207
     const V3 centre = walk(strike, n, 1.0);                       // Sphere.fs:211-220
     for (;;) {
@@ -930,6 +935,13 @@ RTD_INLINE bool reflection_fast(const SceneView<LDS> &sc, int obj, i2 m, V3 stri
         V3 nd;
         if (unitise(vsub(target, strike), nd)) { o = strike; d = nd; break; }
     }
+}
+template <bool LDS>
+RTD_INLINE bool reflection_fast(const SceneView<LDS> &sc, int obj, i2 m, V3 strike, V3 &o, V3 &d, uint32_t &colour, Rng &rng) {
+    const uint32_t texColour = (uint32_t) m.y & 0x00FFFFFFu;
+    if ((((uint32_t) m.x >> 2) & 7u) == 0u) { colour = pix_combine(colour, texColour); return true; } // LightSource, sphere or plane
+    const bool inside = lambert_inside<LDS>(sc, obj, m, o);
+    lambert_bounce<LDS>(sc, obj, m, strike, inside, o, d, colour, rng);
     return false;
 }
 

@@ -48,13 +48,14 @@ struct RenderParams {
     int32_t refill_lanes;          // see Sched: idle lanes are refilled once this many are idle
     int32_t park;                  // entries of a wave's park pool (0: rare styles are shaded in place)
     int32_t park_l;                // entries of a wave's pool of parked LAMBERT hits (0: they are shaded where they fall)
+    int32_t park_l_lds;            // 1: that pool lives in the workgroup's LDS (56-byte entries behind the waves' scratch), 0: in park_pool
     int32_t *accum;                // [n_rows*cols][4]
     uint8_t *rgb;                  // [n_rows*cols][3] or null
     unsigned long long *counters;  // [16]: rays, aabb, prim, refl, samples, pixels_early, -, -, then stage executions (COUNT):
                                    //       [8] refill [9] node trips [10] leaf stages [11] shade stages [12] lanes refilled [13] lanes shaded
                                    //       and, 160 bytes in, [0] slow stages [1] lanes in them [2] lanes parked
     unsigned int *queue;           // work-unit counter of the fused kernel / of pass A, zeroed before launch
-    unsigned char *park_pool;      // [waves of the grid][RTD_PARK_ENTRY_BYTES * (park + park_l)]: per-wave pools of parked paths (see Sched)
+    unsigned char *park_pool;      // [waves of the grid][RTD_PARK_ENTRY_BYTES * (park + (park_l_lds ? 0 : park_l))]: per-wave pools of parked paths (see Sched)
     // two-pass rendering (see render_kernel): pass A appends (cost << 32 | local pixel) for every pixel that continues;
     // pass B walks `live_list` (those pixels ordered by decreasing cost) with its own queue
     unsigned long long *pairs;
@@ -132,6 +133,8 @@ template <> RTD_INLINE SceneView<false> make_view<false, false>(const RenderPara
 struct StageStats { // wave-uniform, COUNT variant only
     uint32_t refill, trips, leaf, shade, refillLanes, shadeLanes, slow, slowLanes, parkedLanes;
     unsigned long long tRefill, tSlow, tWalk, tShade; // shader-clock cycles this wave spent inside each stage (s_memtime)
+    unsigned long long tLoop, tLeaf, tUnb, tCam, tLamb; // -DRTD_STAGE_CLOCKS only: node loop / leaf passes (inside tWalk), unbounded tests (inside tShade),
+                                                        // new items (inside tRefill), Lambert batches (inside tSlow)
 };
 
 // Diagnostic builds (-DRTD_STAGE_CLOCKS): the per-stage cycle sums of the counting variant in the timed variant too
@@ -140,8 +143,8 @@ struct StageStats { // wave-uniform, COUNT variant only
 #else
 #define RTD_CLK false
 #endif
-#define RTD_YIELD_DEFAULT 44
-#define RTD_REFILL_DEFAULT 16
+#define RTD_YIELD_DEFAULT 52
+#define RTD_REFILL_DEFAULT 8
 
 // ---- the lane scheduler shared by every render mode ------------------------------------------------------------------------
 // Every lane of a wave is a path slot in one of four states: IDLE (wants a new item), WALK (somewhere in the tree walk of its
@@ -160,6 +163,7 @@ struct StageStats { // wave-uniform, COUNT variant only
 // (or switched off, p.park = 0) leaves the path in its lane and the general code runs for it at the next turn of the loop.
 // Which lane computes what when has no effect on any result: streams are per item.
 #define RTD_PARK_ENTRY_BYTES 96 /* 5 x 16 B + 8 B, padded */
+#define RTD_PARK_L_LDS_BYTES 56 /* a parked Lambert hit in LDS: strike 24, rng 16, colour, slot, bounces | inside << 31, object */
 enum { L_IDLE = 0, L_WALK = 1, L_DONE = 2, L_SLOW = 3, L_LAMB = 4 };
 
 template <bool LDS, bool COUNT, bool TEX>
@@ -168,7 +172,8 @@ struct Sched {
     const SceneView<LDS> &sc;
     Counters &cnt;
     StageStats &ss;
-    unsigned char *pool; // this wave's park pools: the general one, then the Lambert one
+    unsigned char *pool; // this wave's park pools in global memory: the general one, then (unless it is in LDS) the Lambert one
+    RTD_AS3 unsigned char *poolLds; // this wave's Lambert pool in LDS (p.park_l_lds)
     uint32_t parked;     // entries in the general pool (wave-uniform)
     uint32_t parkedL;    // entries in the Lambert pool (wave-uniform)
     const int end;
@@ -184,8 +189,8 @@ struct Sched {
     bool ended;
     uint32_t result;
 
-    RTD_INLINE Sched(const RenderParams &p_, const SceneView<LDS> &sc_, Counters &cnt_, StageStats &ss_, unsigned char *pool_)
-        : p(p_), sc(sc_), cnt(cnt_), ss(ss_), pool(pool_), parked(0u), parkedL(0u), end(sc_.end) {
+    RTD_INLINE Sched(const RenderParams &p_, const SceneView<LDS> &sc_, Counters &cnt_, StageStats &ss_, unsigned char *pool_, RTD_AS3 unsigned char *poolLds_)
+        : p(p_), sc(sc_), cnt(cnt_), ss(ss_), pool(pool_), poolLds(poolLds_), parked(0u), parkedL(0u), end(sc_.end) {
         st = L_IDLE;
         o = mk(0, 0, 0); d = mk(0, 0, 0);
         walk_begin(w, sc.first); w.off = end; // idle lanes are parked at `end`
@@ -208,6 +213,8 @@ struct Sched {
 
     // a new (pixel, sample) item: Scene.traceOnce's ray (Scene.fs:129-150)
     RTD_INLINE bool start_item(uint64_t pkey, uint32_t sample, int row, int col, uint32_t slot_off) {
+        const unsigned long long k0 = RTD_CLK ? __builtin_amdgcn_s_memtime() : 0ull;
+        struct Stamp { StageStats &ss; unsigned long long k0; RTD_INLINE ~Stamp() { if (RTD_CLK) ss.tCam += __builtin_amdgcn_s_memtime() - k0; } } stamp{ss, k0};
         rng = stream_for(pkey, sample);
         slotOff = slot_off;
         colour = RTD_WHITE;
@@ -250,6 +257,28 @@ struct Sched {
         st = state;
     }
     RTD_INLINE unsigned char *pool_l() const { return pool + (size_t) RTD_PARK_ENTRY_BYTES * (size_t) p.park; }
+    // A parked LAMBERT hit is {strike (in o), inside (bit 31 of bounces), colour, rng, slot, bounces, object}: what lambert_bounce needs.
+    // In LDS: entry e of field f at base + (f * K + e) * 16 (fields 0-2), base + 48 * K + e * 8 (field 3).
+    RTD_INLINE void park_store_lds(uint32_t K, uint32_t e) {
+        RTD_AS3 d2 *f = (RTD_AS3 d2 *) poolLds;
+        d2 v; v.x = o.x; v.y = o.y; f[e] = v;
+        i4 r; r.x = __double2loint(o.z); r.y = __double2hiint(o.z); r.z = (int) colour; r.w = (int) slotOff;
+        ((RTD_AS3 i4 *) poolLds)[K + e] = r;
+        r.x = (int) rng.x; r.y = (int) rng.y; r.z = (int) rng.z; r.w = (int) rng.w;
+        ((RTD_AS3 i4 *) poolLds)[2u * K + e] = r;
+        i2 b; b.x = bounces; b.y = w.best;
+        ((RTD_AS3 i2 *) (poolLds + 48u * K))[e] = b;
+    }
+    RTD_INLINE void park_load_lds(uint32_t K, uint32_t e) {
+        const d2 a = ((const RTD_AS3 d2 *) poolLds)[e];
+        const i4 t = ((const RTD_AS3 i4 *) poolLds)[K + e], r = ((const RTD_AS3 i4 *) poolLds)[2u * K + e];
+        const i2 bo = ((const RTD_AS3 i2 *) (poolLds + 48u * K))[e];
+        o = mk(a.x, a.y, __hiloint2double(t.y, t.x)); colour = (uint32_t) t.z; slotOff = (uint32_t) t.w;
+        rng.x = (uint32_t) r.x; rng.y = (uint32_t) r.y; rng.z = (uint32_t) r.z; rng.w = (uint32_t) r.w;
+        bounces = bo.x; w.best = bo.y;
+        w.off = end;
+        st = L_LAMB;
+    }
     // How the `nIdle` idle lanes of a refill are served (wave-uniform): a FULL batch of parked Lambert hits if that pool holds one,
     // else a full batch of parked general hits, else new items; once there are no new items, whatever the pools still hold.
     RTD_INLINE void unpark_plan(uint32_t nIdle, bool haveNew, uint32_t &nUnL, uint32_t &nUnA) const {
@@ -260,7 +289,11 @@ struct Sched {
     }
     // the idle lane of rank `rank` takes its parked path, if the plan gives it one
     RTD_INLINE bool unpark_lane(uint32_t rank, uint32_t nUnL, uint32_t nUnA) {
-        if (rank < nUnL) { park_load(pool_l(), (uint32_t) p.park_l, parkedL - 1u - rank, L_LAMB); return true; }
+        if (rank < nUnL) {
+            if (p.park_l_lds) park_load_lds((uint32_t) p.park_l, parkedL - 1u - rank);
+            else park_load(pool_l(), (uint32_t) p.park_l, parkedL - 1u - rank, L_LAMB);
+            return true;
+        }
         if (rank < nUnL + nUnA) { park_load(pool, (uint32_t) p.park, parked - 1u - (rank - nUnL), L_SLOW); return true; }
         return false;
     }
@@ -295,10 +328,14 @@ struct Sched {
     // ---- lamb: the Lambert bounce (Sphere.fs:202-222) for the lanes that took parked Lambert hits (or whose hit found the pool full) ----
     RTD_INLINE void stage_lamb() {
         if (__builtin_amdgcn_ballot_w64(st == L_LAMB) == 0ull) return;
-        if (st == L_LAMB) {
-            const V3 strike = walk(o, d, w.bestLen); // Ray.walkAlong ray bestLength (Scene.fs:91)
-            after_reflection(reflection_fast<LDS>(sc, w.best, sc.meta[w.best], strike, o, d, colour, rng));
+        const unsigned long long k0 = RTD_CLK ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (st == L_LAMB) { // o holds the strike point, bit 31 of bounces "the ray came from inside" (stage_shade)
+            const bool inside = bounces < 0;
+            bounces &= 0x7FFFFFFF;
+            lambert_bounce<LDS>(sc, w.best, sc.meta[w.best], o, inside, o, d, colour, rng);
+            after_reflection(false);
         }
+        if (RTD_CLK) ss.tLamb += __builtin_amdgcn_s_memtime() - k0;
     }
 
     // ---- walk: BoundingBox.hits over the tree image, leaf tests deferred out of the node loop ----
@@ -317,9 +354,12 @@ struct Sched {
             const bool implied = p.off.box_implied != 0; // (rays of this kernel are unitised: Ray.make')
             if (RTD_CLK) ss.trips++; // (diagnostic build: walk-stage entries and leaf passes; the loop's trips are not counted)
             for (;;) {
+                const unsigned long long k0 = RTD_CLK ? __builtin_amdgcn_s_memtime() : 0ull;
                 w.off = node_loop_lds32(w.off, pend, end, stop, f);
+                const unsigned long long k1 = RTD_CLK ? __builtin_amdgcn_s_memtime() : 0ull;
                 if (RTD_CLK && __builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) ss.leaf++;
                 if (pend != 0u) leaf_test_object_exact<LDS>(sc, o, d, bestF, w, pend_pop(pend), implied);
+                if (RTD_CLK) { ss.tLoop += k1 - k0; ss.tLeaf += __builtin_amdgcn_s_memtime() - k1; }
                 const bool fin = (st == L_WALK) && (w.off >= end) && pend == 0u;
                 if (fin) st = L_DONE;
                 const int nWalk = __popcll(__builtin_amdgcn_ballot_w64(st == L_WALK));
@@ -359,14 +399,21 @@ struct Sched {
         if (dm == 0ull) return;
         if (COUNT || RTD_CLK) { ss.shade++; ss.shadeLanes += (uint32_t) __popcll(dm); }
         if (st == L_DONE) {
+            const unsigned long long k0 = RTD_CLK ? __builtin_amdgcn_s_memtime() : 0ull;
             unbounded_tests<LDS, COUNT>(sc, o, d, w, cnt);
+            if (RTD_CLK) ss.tUnb += __builtin_amdgcn_s_memtime() - k0;
             if (w.best < 0) { ended = true; result = RTD_BLACK; st = L_IDLE; w.off = end; } // "never heard from again": Black (Scene.fs:102-104)
             else {
                 if (COUNT) cnt.refl++;
                 const i2 m = sc.meta[w.best];
                 if (fast_style(m)) {
-                    if (p.park_l > 0 && (((uint32_t) m.x >> 2) & 7u) != 0u) st = L_LAMB; // an untextured Lambert sphere: parked, bounced in full batches
-                    else {
+                    if (p.park_l > 0 && (((uint32_t) m.x >> 2) & 7u) != 0u) {
+                        // an untextured Lambert sphere: parked as {strike, inside} and bounced in full batches (stage_lamb)
+                        const bool inside = lambert_inside<LDS>(sc, w.best, m, o);
+                        o = walk(o, d, w.bestLen); // Ray.walkAlong ray bestLength (Scene.fs:91)
+                        bounces |= inside ? (int) 0x80000000u : 0;
+                        st = L_LAMB;
+                    } else {
                         const V3 strike = walk(o, d, w.bestLen); // Ray.walkAlong ray bestLength (Scene.fs:91)
                         after_reflection(reflection_fast<LDS>(sc, w.best, m, strike, o, d, colour, rng));
                     }
@@ -389,7 +436,11 @@ struct Sched {
             if (lm != 0ull) {
                 const uint32_t room = (uint32_t) p.park_l - parkedL, want = (uint32_t) __popcll(lm);
                 const uint32_t rank = lane_rank(lm);
-                if (st == L_LAMB && rank < room) { park_store(pool_l(), (uint32_t) p.park_l, parkedL + rank); st = L_IDLE; w.off = end; }
+                if (st == L_LAMB && rank < room) {
+                    if (p.park_l_lds) park_store_lds((uint32_t) p.park_l, parkedL + rank);
+                    else park_store(pool_l(), (uint32_t) p.park_l, parkedL + rank);
+                    st = L_IDLE; w.off = end;
+                }
                 parkedL += want < room ? want : room;
             }
         }
@@ -408,10 +459,10 @@ struct Sched {
 // Trace `total` items of the current unit.  Item i belongs to pixel slot map[i / per] (or i / per when map is null)
 // and is sample s_base + i % per of that pixel; its colour is added to accumulator slot (sample < split ? 0 : 1).
 template <bool LDS, bool COUNT, bool COST, bool TEX>
-RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsigned char *pool, RTD_AS3 uint32_t *acc, const RTD_AS3 uint32_t *pix,
+RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsigned char *pool, RTD_AS3 unsigned char *poolLds, RTD_AS3 uint32_t *acc, const RTD_AS3 uint32_t *pix,
                           const RTD_AS3 uint32_t *live, bool use_live, uint32_t total, uint32_t per, uint32_t s_base,
                           uint32_t split, Counters &cnt, StageStats &ss) {
-    Sched<LDS, COUNT, TEX> L(p, sc, cnt, ss, pool);
+    Sched<LDS, COUNT, TEX> L(p, sc, cnt, ss, pool, poolLds);
     uint32_t next = 0; // wave-uniform
     const bool fastDiv = total < (1u << 22) && per < (1u << 23); // see div_uniform
     const float perRcp = 1.0f / (float) per;
@@ -472,13 +523,13 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsig
 // its last path has ended.  There is no dependency between ranges, so no lane waits at a range boundary -- which is what makes
 // small ranges (good load balance across waves) affordable.  Lane states and stage scheduling are Sched's.
 template <bool LDS, bool COUNT, bool TEX>
-RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsigned char *pool, RTD_AS3 uint32_t *wv, uint32_t n1, uint32_t n2, Counters &cnt,
+RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsigned char *pool, RTD_AS3 unsigned char *poolLds, RTD_AS3 uint32_t *wv, uint32_t n1, uint32_t n2, Counters &cnt,
                            StageStats &ss, uint64_t &sampleCount) {
     const int lane = threadIdx.x & 63;
     const uint32_t P = (uint32_t) p.chunk;
     const uint32_t SW = 7u * P; // words per slot: acc [P][3] then pix [P][4]
     const unsigned long long nList = (unsigned long long) *p.live_count;
-    Sched<LDS, COUNT, TEX> L(p, sc, cnt, ss, pool); // slotOff: word offset from wv of the path's accumulator triple (>= SW: slot 1)
+    Sched<LDS, COUNT, TEX> L(p, sc, cnt, ss, pool, poolLds); // slotOff: word offset from wv of the path's accumulator triple (>= SW: slot 1)
 
     // wave-uniform: the range being handed out (cur) and the one draining (prev)
     unsigned long long curFirst = 0, prevFirst = 0;
@@ -661,7 +712,10 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     RTD_AS3 uint32_t *acc = wv;
     RTD_AS3 uint32_t *pix = wv + 6u * P;
     RTD_AS3 uint32_t *live = pix + 4u * P;
-    unsigned char *pool = p.park_pool + ((size_t) blockIdx.x * (BLOCK / 64) + (size_t) wave) * (size_t) RTD_PARK_ENTRY_BYTES * (size_t) (p.park + p.park_l);
+    unsigned char *pool = p.park_pool + ((size_t) blockIdx.x * (BLOCK / 64) + (size_t) wave) * (size_t) RTD_PARK_ENTRY_BYTES * (size_t) (p.park + (p.park_l_lds ? 0 : p.park_l));
+    // the Lambert pools in LDS (if any) follow the waves' scratch
+    RTD_AS3 unsigned char *poolLds = (RTD_AS3 unsigned char *) (smem + sceneBytes) + (size_t) (BLOCK / 64) * (MODE == 1 ? RTD_WAVE_WORDS_A(P) : RTD_WAVE_WORDS(P)) * 4u +
+                                     (size_t) wave * (size_t) RTD_PARK_L_LDS_BYTES * (size_t) p.park_l;
 
     const uint64_t nLocal = (uint64_t) p.n_rows * (uint64_t) p.cols;
     const uint32_t k = (uint32_t) p.k;
@@ -673,10 +727,11 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     Counters cnt; cnt.rays = cnt.aabb = cnt.prim = cnt.refl = 0;
     StageStats ss; ss.refill = ss.trips = ss.leaf = ss.shade = ss.refillLanes = ss.shadeLanes = ss.slow = ss.slowLanes = ss.parkedLanes = 0;
     ss.tRefill = ss.tSlow = ss.tWalk = ss.tShade = 0ull;
+    ss.tLoop = ss.tLeaf = ss.tUnb = ss.tCam = ss.tLamb = 0ull;
     uint32_t earlyCount = 0;
     uint64_t sampleCount = 0; // Scene.traceOnce calls = sum of PixelStats.Count
 
-    if (MODE == 2) run_stream<LDS, COUNT, TEX>(p, sc, pool, wv, n1, n2, cnt, ss, sampleCount);
+    if (MODE == 2) run_stream<LDS, COUNT, TEX>(p, sc, pool, poolLds, wv, n1, n2, cnt, ss, sampleCount);
     else
     for (;;) {
         uint32_t unit = 0;
@@ -704,7 +759,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
         __builtin_amdgcn_wave_barrier();
 
         // ---- phase 1: 2k+1 samples per pixel, sums split after sample k (Scene.fs:172-182) ----
-        run_items<LDS, COUNT, MODE == 1, TEX>(p, sc, pool, acc, pix, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
+        run_items<LDS, COUNT, MODE == 1, TEX>(p, sc, pool, poolLds, acc, pix, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
         __builtin_amdgcn_wave_barrier();
 
         // ---- decide (Scene.fs:177-188) and compact the pixels that continue ----
@@ -739,7 +794,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
 
         // ---- phase 2: the remaining spp-2k-1 samples of the surviving pixels (Scene.fs:191-192) ----
         if (MODE == 0 && nLive > 0u) {
-            run_items<LDS, COUNT, false, TEX>(p, sc, pool, acc, pix, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
+            run_items<LDS, COUNT, false, TEX>(p, sc, pool, poolLds, acc, pix, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
             __builtin_amdgcn_wave_barrier();
         }
 
@@ -792,6 +847,13 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
         atomicAdd(&p.counters[24], ss.tSlow);
         atomicAdd(&p.counters[25], ss.tWalk);
         atomicAdd(&p.counters[26], ss.tShade);
+        if (RTD_CLK) {
+            atomicAdd(&p.counters[27], ss.tLoop);
+            atomicAdd(&p.counters[28], ss.tLeaf);
+            atomicAdd(&p.counters[29], ss.tUnb);
+            atomicAdd(&p.counters[30], ss.tCam);
+            atomicAdd(&p.counters[31], ss.tLamb);
+        }
     }
     if (lane == 0) {
         atomicAdd(&p.counters[4], (unsigned long long) s);

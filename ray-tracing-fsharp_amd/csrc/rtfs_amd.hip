@@ -143,6 +143,22 @@ static const char *check_settings(const Settings &s) {
 static size_t lds_need(const rth::HostScene &h, bool lds, bool count, int block, int chunk, bool passA = false) {
     return (lds ? (size_t) (count ? h.off.lds_total : h.off.lds32_total) : 0u) + (size_t) (block / 64) * (passA ? RTD_WAVE_WORDS_A(chunk) : RTD_WAVE_WORDS(chunk)) * 4u;
 }
+// The Lambert pool in LDS: as many 56-byte entries per wave as fit beside the scene and the waves' scratch, at most 64; with room
+// for fewer than 32 the pool stays in global memory (entries of RTD_PARK_ENTRY_BYTES, L2-resident at best).  Returns the capacity
+// and adds the pools' bytes to ldsBytes.
+static int lambert_pool_lds(size_t &ldsBytes, int block) {
+#ifdef RTD_NO_LDS_POOL
+    return 0;
+#endif
+    if (ldsBytes >= RT_LDS_BYTES) return 0;
+    const size_t waves = (size_t) block / 64u;
+    size_t c = (RT_LDS_BYTES - ldsBytes) / (waves * RTD_PARK_L_LDS_BYTES);
+    if (c > 64) c = 64;
+    c &= ~(size_t) 1; // an even capacity keeps every field array 16-byte aligned
+    if (c < 32) return 0;
+    ldsBytes += waves * RTD_PARK_L_LDS_BYTES * c;
+    return (int) c;
+}
 struct LaunchPlan {
     int block = 1024, chunk = 16, park = 0;
     bool lds = false;
@@ -461,7 +477,11 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
 
     const bool tex = !h.texRecs.empty();
     render_fn fn = pick_kernel(lds, count, block, 0, tex);
-    const size_t ldsBytes = lds_need(h, lds, count, block, chunk);
+    size_t ldsBytes = lds_need(h, lds, count, block, chunk);
+    if (p.park_l > 0) { // the fused launch's Lambert pool: in LDS if it fits (the two-pass launches decide for themselves below)
+        const int cl = lambert_pool_lds(ldsBytes, block);
+        if (cl) { p.park_l = cl; p.park_l_lds = 1; }
+    }
     HIP_TRY(hipFuncSetAttribute((const void *) fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes));
     int perCu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, (const void *) fn, block, ldsBytes));
@@ -488,7 +508,7 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
     // launch that uses them, so no launch shares state with another and the call returns without waiting for the device.
     const size_t pairsBytes = twoPass ? (((size_t) nLocal * 8u + 15u) & ~(size_t) 15u) : 0u, listBytes = twoPass ? (((size_t) nLocal * 4u + 15u) & ~(size_t) 15u) : 0u;
     const size_t sortBytes = twoPass ? (3u * RTD_COST_BUCKETS * 4u + 15u) & ~(size_t) 15u : 0u;
-    const size_t poolBytes = (size_t) (twoPass ? fullGrid : grid) * (size_t) wavesPerBlock * (size_t) RTD_PARK_ENTRY_BYTES * (size_t) (p.park + p.park_l);
+    const size_t poolBytes = (size_t) (twoPass ? fullGrid : grid) * (size_t) wavesPerBlock * (size_t) RTD_PARK_ENTRY_BYTES * (size_t) (p.park + (p.park > 0 ? RTD_PARK_L_DEFAULT : 0));
     unsigned char *scr = nullptr;
     if (grid > 0 || stats) HIP_TRY(hipMallocAsync((void **) &scr, RT_SCRATCH_BYTES + pairsBytes + listBytes + sortBytes + poolBytes, st));
     Pending &cl = pd; // on every exit path its destructor (or collect_stats) gives the scratch back
@@ -535,12 +555,16 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
             // pass A would leave a half-rendered buffer); 
             while (lds && chunkA > 1 && lds_need(h, true, count, block, chunkA, true) > RT_LDS_BYTES) chunkA /= 2;
             while (lds && chunkB > 1 && lds_need(h, true, count, block, chunkB) > RT_LDS_BYTES) chunkB /= 2;
-            const size_t ldsA = lds_need(h, lds, count, block, chunkA, true), ldsB = lds_need(h, lds, count, block, chunkB);
+            size_t ldsA = lds_need(h, lds, count, block, chunkA, true), ldsB = lds_need(h, lds, count, block, chunkB);
             if (lds && (ldsA > RT_LDS_BYTES || ldsB > RT_LDS_BYTES)) return fail(RT_ERR_HIP, "two-pass launch does not fit the LDS");
+            int clA = 0, clB = 0;
+            if (plan.park > 0) { clA = lambert_pool_lds(ldsA, block); clB = lambert_pool_lds(ldsB, block); }
             HIP_TRY(hipFuncSetAttribute((const void *) fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsA));
             HIP_TRY(hipFuncSetAttribute((const void *) fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsB));
             RenderParams pa = p;
             pa.chunk = chunkA;
+            pa.park_l = clA ? clA : (plan.park > 0 ? RTD_PARK_L_DEFAULT : 0); pa.park_l_lds = clA ? 1 : 0;
+            p.park_l = clB ? clB : (plan.park > 0 ? RTD_PARK_L_DEFAULT : 0); p.park_l_lds = clB ? 1 : 0;
             const uint64_t unitsA = (nLocal + (uint64_t) chunkA - 1) / (uint64_t) chunkA;
             uint64_t gridA = (unitsA + wavesPerBlock - 1) / wavesPerBlock;
             if (gridA > fullGrid) gridA = fullGrid;
@@ -569,8 +593,12 @@ static int collect_stats(Pending &pd, rt_stats *stats) {
     unsigned long long c[32] = {0};
     if (pd.scr) {
         HIP_TRY(hipMemcpy(c, pd.scr, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(c + 16, pd.scr + 160, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(c + 16, pd.scr + 160, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
+#ifdef RTD_STAGE_CLOCKS
+    if (getenv("RTFS_STAGE_CLOCKS")) // diagnostic build: the finer clocks of rt_render_kernel.h's StageStats
+        fprintf(stderr, "stage clocks: loop %llu leaf %llu unbounded %llu new_items %llu lambert %llu\n", c[23], c[24], c[25], c[26], c[27]);
+#endif
     for (int i = 0; i < 6; ++i) g_last_stage_stats[i] = c[8 + i];
     g_last_stage_stats[6] = c[14];                                  // sum of wave lifetimes, 100 MHz ticks
     g_last_stage_stats[7] = c[15] - (0x4000000000000000ull - c[7]); // first wave start -> last wave end, ticks
