@@ -712,8 +712,11 @@ RTD_INLINE uint32_t ramp_byte(double v) { // byte (v * 255.0) (RayTracing.App/Sa
     const double t = v * 255.0;
     return (t == t) ? (((uint32_t) (int32_t) t) & 0xFFu) : 0u;
 }
-// Rare (only textured spheres), transcendental-heavy (double-double arithmetic, rt_trig.h): kept out of line so the common path stays small.
-__device__ __noinline__ uint32_t texture_colour_at(const TexRec *tex, const uint8_t *texels, int id, V3 p, double *uv) {
+// Rare (only textured spheres), transcendental-heavy (double-double arithmetic, rt_trig.h).  The render kernel evaluates it INLINE in a
+// stage of its own (stage_tex): a call anywhere in the kernel's loop makes every value that lives across it compete for the few
+// callee-saved registers (measured: 136 SGPR and 40 VGPR spills against 17 and 0 without the call, config 5 25 % slower).
+// The unit hooks and the single-lane helpers call the out-of-line copy below.
+RTD_INLINE uint32_t texture_colour_at_inline(const TexRec *tex, const uint8_t *texels, int id, V3 p, double *uv) {
     const TexRec root = tex[id];
     if (root.kind == 0u) return root.rgb; // ParameterisedTexture.toTexture's Colour case (Texture.fs:71)
     double inv = 1.0 / root.map_radius;
@@ -753,6 +756,9 @@ __device__ __noinline__ uint32_t texture_colour_at(const TexRec *tex, const uint
     }
     return RTD_BLACK;
 }
+__device__ __noinline__ uint32_t texture_colour_at(const TexRec *tex, const uint8_t *texels, int id, V3 p, double *uv) {
+    return texture_colour_at_inline(tex, texels, id, p, uv);
+}
 
 // ---- Hittable.Reflection (Hittable.fs:8-12 -> Sphere.reflection Sphere.fs:150-300, InfinitePlane.reflection
 //      InfinitePlane.fs:43-99) --------------------------------------------------------------------------------
@@ -761,11 +767,23 @@ __device__ __noinline__ uint32_t texture_colour_at(const TexRec *tex, const uint
 // stage once, so Pure/Fuzzed/Dielectric/Glass spheres and Pure/Fuzzed planes all share one mirror computation.
 enum { ACT_REFLECT = 1, ACT_REFRACT = 2, ACT_FUZZ = 4, ACT_LAMBERT = 8, ACT_LAMBERT_ONCE = 16 };
 
-// TEX = false compiles the function without the (out-of-line) texture evaluation, for scenes that have no parameterised
-// texture: the call is what costs the render kernel its spills (with it: 128 VGPRs, ~50 VGPR and ~115 SGPR spills, 204 B of
-// scratch; without: 0 scratch, 0 VGPR spills, 9 SGPR spills for the pass-B instantiation).
+// TEX = false compiles the function without the (out-of-line) texture evaluation: for scenes that have no parameterised texture,
+// and for the render kernel, which evaluates textures in a stage of their own (rt_render_kernel.h, stage_tex) and hands the colour
+// over in `texPre` (RTD_NO_TEX: the object's plain colour applies).  A texture call in the middle of the general reflection cost
+// the kernel its spills (128 VGPRs, ~50 VGPR and ~115 SGPR spills, 204 B of scratch) and ran the whole double-double evaluation for
+// the one or two textured lanes of almost every batch.
+#define RTD_NO_TEX 0xFFFFFFFFu
+// does the hit object's colour come from a parameterised texture?  Styles that carry a Texture: every SphereStyle but LightSourceCap
+// (Sphere.fs:10-37), and the plane LightSource (InfinitePlane.fs:5); the other plane styles carry a plain Pixel (the host rejects a
+// texture id elsewhere).  Returns the texture's id or -1.
+RTD_INLINE int textured(i2 m) {
+    const int texId = (int) (((uint32_t) m.y) >> 24) - 1;
+    const bool isPlane = (m.x & 3) == (int) RTD_KIND_PLANE;
+    const int style = (m.x >> 2) & 7;
+    return (texId >= 0 && (isPlane ? style == 0 : style != 1)) ? texId : -1;
+}
 template <bool LDS, bool TEX = true>
-RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, V3 &d, uint32_t &colour, Rng &rng) {
+RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, V3 &d, uint32_t &colour, Rng &rng, uint32_t texPre = RTD_NO_TEX) {
     const i2 m = sc.meta[obj];
     const bool isPlane = (m.x & 3) == (int) RTD_KIND_PLANE;
     const int style = (m.x >> 2) & 7;
@@ -773,11 +791,11 @@ RTD_INLINE bool reflection(const SceneView<LDS> &sc, int obj, V3 strike, V3 &o, 
     const double m0 = sc.mat[obj * 4 + 0], p1 = sc.mat[obj * 4 + 1], p2 = sc.mat[obj * 4 + 2], p3 = sc.mat[obj * 4 + 3];
     const double albedo = isPlane ? m0 : g2.x; // a sphere's albedo rides in its geo record (the common Lambert case never reads `mat`)
     uint32_t texColour = (uint32_t) m.y & 0x00FFFFFFu;
-    const int texId = (int) (((uint32_t) m.y) >> 24) - 1;
-    // Styles that carry a Texture: every SphereStyle but LightSourceCap (Sphere.fs:10-37), and the plane LightSource
-    // (InfinitePlane.fs:5); the other plane styles carry a plain Pixel.  The host rejects a texture id elsewhere.
-    if (TEX && texId >= 0 && (isPlane ? style == 0 : style != 1))
-        texColour = texture_colour_at(sc.tex, sc.texels, texId, strike, nullptr);
+    if (texPre != RTD_NO_TEX) texColour = texPre;
+    else if (TEX) {
+        const int texId = textured(m);
+        if (texId >= 0) texColour = texture_colour_at(sc.tex, sc.texels, texId, strike, nullptr);
+    }
 
     V3 n;              // normal.Vector (possibly flipped)
     bool inside = false;

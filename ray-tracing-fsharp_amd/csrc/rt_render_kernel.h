@@ -164,7 +164,7 @@ struct StageStats { // wave-uniform, COUNT variant only
 // Which lane computes what when has no effect on any result: streams are per item.
 #define RTD_PARK_ENTRY_BYTES 96 /* 5 x 16 B + 8 B, padded */
 #define RTD_PARK_L_LDS_BYTES 56 /* a parked Lambert hit in LDS: strike 24, rng 16, colour, slot, bounces | inside << 31, object */
-enum { L_IDLE = 0, L_WALK = 1, L_DONE = 2, L_SLOW = 3, L_LAMB = 4 };
+enum { L_IDLE = 0, L_WALK = 1, L_DONE = 2, L_SLOW = 3, L_LAMB = 4, L_TEX = 5 };
 
 template <bool LDS, bool COUNT, bool TEX>
 struct Sched {
@@ -176,6 +176,7 @@ struct Sched {
     RTD_AS3 unsigned char *poolLds; // this wave's Lambert pool in LDS (p.park_l_lds)
     uint32_t parked;     // entries in the general pool (wave-uniform)
     uint32_t parkedL;    // entries in the Lambert pool (wave-uniform)
+    uint32_t parkedT;    // entries in the pool of hits whose colour is a parameterised texture (TEX kernels only; wave-uniform)
     const int end;
     // lane state
     int st;
@@ -185,17 +186,18 @@ struct Sched {
     uint32_t colour, slotOff;
     int bounces;
     uint32_t pend; // queue of pending leaf tests (node_loop_lds); always 0 outside a walk and in the variants that do not queue
+    uint32_t texc; // L_SLOW lanes: the hit's texture colour if stage_tex has evaluated one, else RTD_NO_TEX
     // set by the stages for the caller's bookkeeping: this lane's path ended during the current turn, with this colour
     bool ended;
     uint32_t result;
 
     RTD_INLINE Sched(const RenderParams &p_, const SceneView<LDS> &sc_, Counters &cnt_, StageStats &ss_, unsigned char *pool_, RTD_AS3 unsigned char *poolLds_)
-        : p(p_), sc(sc_), cnt(cnt_), ss(ss_), pool(pool_), poolLds(poolLds_), parked(0u), parkedL(0u), end(sc_.end) {
+        : p(p_), sc(sc_), cnt(cnt_), ss(ss_), pool(pool_), poolLds(poolLds_), parked(0u), parkedL(0u), parkedT(0u), end(sc_.end) {
         st = L_IDLE;
         o = mk(0, 0, 0); d = mk(0, 0, 0);
         walk_begin(w, sc.first); w.off = end; // idle lanes are parked at `end`
         rng.x = rng.y = rng.z = rng.w = 0;
-        colour = 0; slotOff = 0; bounces = 0; pend = 0u;
+        colour = 0; slotOff = 0; bounces = 0; pend = 0u; texc = RTD_NO_TEX;
         ended = false; result = 0;
     }
 
@@ -257,6 +259,7 @@ struct Sched {
         st = state;
     }
     RTD_INLINE unsigned char *pool_l() const { return pool + (size_t) RTD_PARK_ENTRY_BYTES * (size_t) p.park; }
+    RTD_INLINE unsigned char *pool_t() const { return pool + (size_t) RTD_PARK_ENTRY_BYTES * (size_t) (p.park + (p.park_l_lds ? 0 : p.park_l)); } // capacity p.park
     // A parked LAMBERT hit is {strike (in o), inside (bit 31 of bounces), colour, rng, slot, bounces, object}: what lambert_bounce needs.
     // In LDS: entry e of field f at base + (f * K + e) * 16 (fields 0-2), base + 48 * K + e * 8 (field 3).
     RTD_INLINE void park_store_lds(uint32_t K, uint32_t e) {
@@ -281,20 +284,26 @@ struct Sched {
     }
     // How the `nIdle` idle lanes of a refill are served (wave-uniform): a FULL batch of parked Lambert hits if that pool holds one,
     // else a full batch of parked general hits, else new items; once there are no new items, whatever the pools still hold.
-    RTD_INLINE void unpark_plan(uint32_t nIdle, bool haveNew, uint32_t &nUnL, uint32_t &nUnA) const {
-        nUnL = nUnA = 0u;
+    RTD_INLINE void unpark_plan(uint32_t nIdle, bool haveNew, uint32_t &nUnL, uint32_t &nUnA, uint32_t &nUnT) const {
+        nUnL = nUnA = nUnT = 0u;
         if (parkedL >= nIdle) nUnL = nIdle;
         else if (parked >= nIdle) nUnA = nIdle;
-        else if (!haveNew) { nUnL = parkedL; nUnA = parked < nIdle - nUnL ? parked : nIdle - nUnL; }
+        else if (TEX && parkedT >= nIdle) nUnT = nIdle;
+        else if (!haveNew) {
+            nUnL = parkedL;
+            nUnA = parked < nIdle - nUnL ? parked : nIdle - nUnL;
+            if (TEX) nUnT = parkedT < nIdle - nUnL - nUnA ? parkedT : nIdle - nUnL - nUnA;
+        }
     }
     // the idle lane of rank `rank` takes its parked path, if the plan gives it one
-    RTD_INLINE bool unpark_lane(uint32_t rank, uint32_t nUnL, uint32_t nUnA) {
+    RTD_INLINE bool unpark_lane(uint32_t rank, uint32_t nUnL, uint32_t nUnA, uint32_t nUnT) {
         if (rank < nUnL) {
             if (p.park_l_lds) park_load_lds((uint32_t) p.park_l, parkedL - 1u - rank);
             else park_load(pool_l(), (uint32_t) p.park_l, parkedL - 1u - rank, L_LAMB);
             return true;
         }
-        if (rank < nUnL + nUnA) { park_load(pool, (uint32_t) p.park, parked - 1u - (rank - nUnL), L_SLOW); return true; }
+        if (rank < nUnL + nUnA) { park_load(pool, (uint32_t) p.park, parked - 1u - (rank - nUnL), L_SLOW); texc = RTD_NO_TEX; return true; }
+        if (TEX && rank < nUnL + nUnA + nUnT) { park_load(pool_t(), (uint32_t) p.park, parkedT - 1u - (rank - nUnL - nUnA), L_TEX); return true; }
         return false;
     }
 
@@ -321,7 +330,20 @@ struct Sched {
         if (COUNT || RTD_CLK) { ss.slow++; ss.slowLanes += (uint32_t) __popcll(m); }
         if (st == L_SLOW) {
             const V3 strike = walk(o, d, w.bestLen); // Ray.walkAlong ray bestLength (Scene.fs:91)
-            after_reflection(reflection<LDS, TEX>(sc, w.best, strike, o, d, colour, rng));
+            after_reflection(reflection<LDS, false>(sc, w.best, strike, o, d, colour, rng, TEX ? texc : RTD_NO_TEX));
+        }
+    }
+
+    // ---- tex: Texture.colourAt (Texture.fs:50-67) for the lanes that took parked textured hits (or whose hit found that pool full).
+    // The evaluation is long (correctly rounded acos / atan2 / sin in double-double, rt_trig.h); here it runs for a batch of lanes
+    // at once, inline, and nowhere else in the kernel.  The lane goes on to the general reflection with the colour in `texc`.
+    RTD_INLINE void stage_tex() {
+        if (!TEX) return;
+        if (__builtin_amdgcn_ballot_w64(st == L_TEX) == 0ull) return;
+        if (st == L_TEX) {
+            const V3 strike = walk(o, d, w.bestLen);
+            texc = texture_colour_at_inline(sc.tex, sc.texels, textured(sc.meta[w.best]), strike, nullptr);
+            st = L_SLOW;
         }
     }
 
@@ -417,7 +439,17 @@ struct Sched {
                         const V3 strike = walk(o, d, w.bestLen); // Ray.walkAlong ray bestLength (Scene.fs:91)
                         after_reflection(reflection_fast<LDS>(sc, w.best, m, strike, o, d, colour, rng));
                     }
-                } else st = L_SLOW;
+                } else if (TEX && textured(m) >= 0) st = L_TEX;
+                else { st = L_SLOW; texc = RTD_NO_TEX; }
+            }
+        }
+        if (TEX && p.park > 0) {
+            const unsigned long long tm = __builtin_amdgcn_ballot_w64(st == L_TEX);
+            if (tm != 0ull) {
+                const uint32_t room = (uint32_t) p.park - parkedT, want = (uint32_t) __popcll(tm);
+                const uint32_t rank = lane_rank(tm);
+                if (st == L_TEX && rank < room) { park_store(pool_t(), (uint32_t) p.park, parkedT + rank); st = L_IDLE; w.off = end; }
+                parkedT += want < room ? want : room;
             }
         }
         if (p.park > 0) {
@@ -472,15 +504,15 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsig
         // ---- refill: idle lanes take parked paths or the next items of the unit ----
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(L.st == L_IDLE);
         const bool haveNew = next < total;
-        if (idle != 0ull && (haveNew || (L.parked | L.parkedL) != 0u) && (__popcll(idle) >= p.refill_lanes || ~idle == 0ull)) {
+        if (idle != 0ull && (haveNew || (L.parked | L.parkedL | L.parkedT) != 0u) && (__popcll(idle) >= p.refill_lanes || ~idle == 0ull)) {
             const uint32_t nIdle = (uint32_t) __popcll(idle);
             const uint32_t rank = lane_rank(idle);
-            uint32_t nUnL, nUnA;
-            L.unpark_plan(nIdle, haveNew, nUnL, nUnA);
-            const uint32_t nUn = nUnL + nUnA;
+            uint32_t nUnL, nUnA, nUnT;
+            L.unpark_plan(nIdle, haveNew, nUnL, nUnA, nUnT);
+            const uint32_t nUn = nUnL + nUnA + nUnT;
             if (COUNT || RTD_CLK) { ss.refill++; ss.refillLanes += nIdle; }
             if (L.st == L_IDLE) {
-                if (!L.unpark_lane(rank, nUnL, nUnA)) {
+                if (!L.unpark_lane(rank, nUnL, nUnA, nUnT)) {
                     const uint32_t item = next + (rank - nUn);
                     if (item < total) {
                         uint32_t j = fastDiv ? div_uniform(item, per, perRcp) : item / per;
@@ -495,14 +527,16 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsig
             }
             L.parked -= nUnA;
             L.parkedL -= nUnL;
+            L.parkedT -= nUnT;
             next += nIdle - nUn;
             next = __builtin_amdgcn_readfirstlane(next);
         }
         if (__builtin_amdgcn_ballot_w64(L.st != L_IDLE) == 0ull) {
-            if (next >= total && (L.parked | L.parkedL) == 0u) break;
+            if (next >= total && (L.parked | L.parkedL | L.parkedT) == 0u) break;
             continue;
         }
         const unsigned long long t1 = (COUNT || RTD_CLK) ? __builtin_amdgcn_s_memtime() : 0ull;
+        L.stage_tex();
         L.stage_slow();
         L.stage_lamb();
         const unsigned long long t2 = (COUNT || RTD_CLK) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -615,17 +649,17 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
         {
             const uint32_t nIdle = (uint32_t) __popcll(idle);
             const uint32_t avail = curTotal - curNext;
-            if (nIdle != 0u && (avail != 0u || (L.parked | L.parkedL) != 0u) && ((int) nIdle >= p.refill_lanes || nIdle == 64u)) {
+            if (nIdle != 0u && (avail != 0u || (L.parked | L.parkedL | L.parkedT) != 0u) && ((int) nIdle >= p.refill_lanes || nIdle == 64u)) {
                 const uint32_t rank = lane_rank(idle);
-                uint32_t nUnL, nUnA;
-                L.unpark_plan(nIdle, avail != 0u, nUnL, nUnA);
-                const uint32_t nUn = nUnL + nUnA;
+                uint32_t nUnL, nUnA, nUnT;
+                L.unpark_plan(nIdle, avail != 0u, nUnL, nUnA, nUnT);
+                const uint32_t nUn = nUnL + nUnA + nUnT;
                 if (COUNT || RTD_CLK) { ss.refill++; ss.refillLanes += nIdle; }
                 const uint32_t rest = nIdle - nUn;
                 const uint32_t take = rest < avail ? rest : avail;
                 bool started = false;
                 if (L.st == L_IDLE) {
-                    if (!L.unpark_lane(rank, nUnL, nUnA) && rank - nUn < take) {
+                    if (!L.unpark_lane(rank, nUnL, nUnA, nUnT) && rank - nUn < take) {
                         const uint32_t item = curNext + (rank - nUn);
                         const uint32_t j = fastDiv ? div_uniform(item, n2, perRcp) : item / n2;
                         const uint32_t smp = n1 + (item - j * n2);
@@ -637,6 +671,7 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
                 }
                 L.parked -= nUnA;
                 L.parkedL -= nUnL;
+                L.parkedT -= nUnT;
                 curNext += take;
                 curOut += (uint32_t) __popcll(__builtin_amdgcn_ballot_w64(started));
             }
@@ -644,6 +679,7 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
         if (__builtin_amdgcn_ballot_w64(L.st != L_IDLE) == 0ull) continue;
 
         const unsigned long long t1 = (COUNT || RTD_CLK) ? __builtin_amdgcn_s_memtime() : 0ull;
+        L.stage_tex();
         L.stage_slow();
         L.stage_lamb();
         const unsigned long long t2 = (COUNT || RTD_CLK) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -703,7 +739,10 @@ RTD_INLINE uint32_t stage_scene(const RenderParams &p, unsigned char *smem) {
 template <bool LDS, bool COUNT, int BLOCK, int MODE, bool TEX>
 __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // the wave's index as a SCALAR: everything derived from it (the wave's LDS scratch, its park pools) then has a scalar base, and the
+    // pools' field addresses are scalar base + 32-bit lane offset instead of 64-bit vector arithmetic kept alive across the loop
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
 
     const uint32_t sceneBytes = LDS ? stage_scene<BLOCK, !COUNT>(p, smem) : 0u;
     const SceneView<LDS> sc = make_view<LDS, LDS && !COUNT>(p, smem);
@@ -712,7 +751,8 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     RTD_AS3 uint32_t *acc = wv;
     RTD_AS3 uint32_t *pix = wv + 6u * P;
     RTD_AS3 uint32_t *live = pix + 4u * P;
-    unsigned char *pool = p.park_pool + ((size_t) blockIdx.x * (BLOCK / 64) + (size_t) wave) * (size_t) RTD_PARK_ENTRY_BYTES * (size_t) (p.park + (p.park_l_lds ? 0 : p.park_l));
+    unsigned char *pool = p.park_pool + ((size_t) blockIdx.x * (BLOCK / 64) + (size_t) wave) * (size_t) RTD_PARK_ENTRY_BYTES *
+                                        (size_t) (p.park + (p.park_l_lds ? 0 : p.park_l) + (TEX ? p.park : 0));
     // the Lambert pools in LDS (if any) follow the waves' scratch
     RTD_AS3 unsigned char *poolLds = (RTD_AS3 unsigned char *) (smem + sceneBytes) + (size_t) (BLOCK / 64) * (MODE == 1 ? RTD_WAVE_WORDS_A(P) : RTD_WAVE_WORDS(P)) * 4u +
                                      (size_t) wave * (size_t) RTD_PARK_L_LDS_BYTES * (size_t) p.park_l;

@@ -508,7 +508,8 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
     // launch that uses them, so no launch shares state with another and the call returns without waiting for the device.
     const size_t pairsBytes = twoPass ? (((size_t) nLocal * 8u + 15u) & ~(size_t) 15u) : 0u, listBytes = twoPass ? (((size_t) nLocal * 4u + 15u) & ~(size_t) 15u) : 0u;
     const size_t sortBytes = twoPass ? (3u * RTD_COST_BUCKETS * 4u + 15u) & ~(size_t) 15u : 0u;
-    const size_t poolBytes = (size_t) (twoPass ? fullGrid : grid) * (size_t) wavesPerBlock * (size_t) RTD_PARK_ENTRY_BYTES * (size_t) (p.park + (p.park > 0 ? RTD_PARK_L_DEFAULT : 0));
+    const size_t poolBytes = (size_t) (twoPass ? fullGrid : grid) * (size_t) wavesPerBlock * (size_t) RTD_PARK_ENTRY_BYTES *
+                             (size_t) (p.park + (p.park > 0 ? RTD_PARK_L_DEFAULT : 0) + (tex ? p.park : 0)); // general + Lambert (unless in LDS) + textured
     unsigned char *scr = nullptr;
     if (grid > 0 || stats) HIP_TRY(hipMallocAsync((void **) &scr, RT_SCRATCH_BYTES + pairsBytes + listBytes + sortBytes + poolBytes, st));
     Pending &cl = pd; // on every exit path its destructor (or collect_stats) gives the scratch back
