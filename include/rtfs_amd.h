@@ -178,8 +178,11 @@ int rt_scene_get_walk_tree(const rt_scene *scene, int32_t *skip, int32_t *prim, 
  * every arriving ray hits are not tested at all (their children take their place; csrc/rt_scene.h "thinning").  Every pixel
  * stays the same bit for bit, as under rt_set_walk_tree and for the same reason; what changes is aabb_tests (final scene:
  * 23.8 -> about 17 per ray) and the frame time.  rt_scene_get_walk_tree then reports an n-ary tree in the same pre-order/skip
- * form, rt_scene_get_info.walk_tree = RT_WALK_TREE_TUNED, n_nodes shrinks.  The probe is deterministic (which rays are logged
- * depends on their random streams only, and the log is sorted), so the same call yields the same tree.
+ * form, rt_scene_get_info.walk_tree = RT_WALK_TREE_TUNED, walk_tree_nodes shrinks (n_nodes stays the size of BoundingBoxTree.make's
+ * own tree; size rt_scene_get_walk_tree's arrays by walk_tree_nodes).  The probe is deterministic (which rays are logged depends
+ * on their random streams only, and the log is sorted), so the same call yields the same tree; a probe whose log still overflows
+ * after being thinned to one ray in 2^20 would hold a scheduling-dependent subset, and such a scene is left untuned (tuned = 0).
+ * The replacement is failure-atomic: host tree and device copies change together or not at all.
  * A scene that walks the reference's own tree (RT_WALK_TREE_REFERENCE, or fewer than 3 bounded spheres, or non-finite boxes)
  * is left alone: tuned = 0.  Must not run concurrently with renders of the same scene: it replaces the device images (after
  * waiting for the devices that hold one).  Typical use: once after rt_scene_create, with the camera and image size of the

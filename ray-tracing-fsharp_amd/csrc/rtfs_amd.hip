@@ -658,19 +658,34 @@ static int apply_tune(rt_scene *scene, const std::vector<RawRay> &raw, rt_tune_i
     rth::TuneResult tr;
     std::lock_guard<std::mutex> lock(scene->mu);
     rth::HostScene &h = scene->host;
+    // Failure-atomic: the host tree and every device copy change together or not at all.  The new image is uploaded to fresh
+    // allocations first; only when every device has its copy are the old ones released and the pointers swapped.  On any failure
+    // the host scene is put back as it was and the new allocations are freed, so no launch can pair an old image with new offsets.
+    struct Saved { rth::FlatTree walkTree; int walkKind; std::vector<unsigned char> image; rtd::SceneOffsets off; } saved{h.walkTree, h.walkKind, h.image, h.off};
     if (!rth::tune_walk_tree(h, rays, tr)) return RT_OK; // a reference-tree scene, or no rays: left as it is
     if (!scene->dev.empty()) {
         int prev = -1;
-        HIP_TRY(hipGetDevice(&prev));
+        if (hipGetDevice(&prev) != hipSuccess) { (void) hipGetLastError(); prev = -1; }
+        struct Restore { int prev; ~Restore() { if (prev >= 0) (void) hipSetDevice(prev); } } restore{prev};
+        std::vector<std::pair<int, unsigned char *>> fresh;
+        hipError_t err = hipSuccess;
         for (auto &kv : scene->dev) {
-            HIP_TRY(hipSetDevice(kv.first));
-            HIP_TRY(hipDeviceSynchronize());
-            (void) hipFree(kv.second.image);
-            kv.second.image = nullptr;
-            HIP_TRY(hipMalloc((void **) &kv.second.image, h.image.size()));
-            HIP_TRY(hipMemcpy(kv.second.image, h.image.data(), h.image.size(), hipMemcpyHostToDevice));
+            unsigned char *img = nullptr;
+            err = hipSetDevice(kv.first);
+            if (err == hipSuccess) err = hipMalloc((void **) &img, h.image.size());
+            if (err == hipSuccess) { fresh.emplace_back(kv.first, img); err = hipMemcpy(img, h.image.data(), h.image.size(), hipMemcpyHostToDevice); }
+            if (err != hipSuccess) break;
         }
-        HIP_TRY(hipSetDevice(prev));
+        if (err != hipSuccess) {
+            for (auto &f : fresh) if (hipSetDevice(f.first) == hipSuccess) (void) hipFree(f.second);
+            h.walkTree = std::move(saved.walkTree); h.walkKind = saved.walkKind; h.image = std::move(saved.image); h.off = saved.off;
+            return fail(RT_ERR_HIP, std::string("rt_scene_tune: uploading the rebuilt image: ") + hipGetErrorString(err));
+        }
+        for (auto &f : fresh) { // every device has the new image: let each finish what it was doing with the old one, then swap
+            DeviceScene &d = scene->dev[f.first];
+            if (hipSetDevice(f.first) == hipSuccess) { (void) hipDeviceSynchronize(); (void) hipFree(d.image); }
+            d.image = f.second;
+        }
     }
     out.tuned = 1;
     out.probe_rays = (int32_t) rays.size();
@@ -716,7 +731,7 @@ int rt_scene_tune(rt_scene *scene, const rt_camera *camera, int32_t max_w, int32
     HIP_TRY(hipMalloc((void **) &b.rays, (size_t) cap * 48u));
     HIP_TRY(hipMalloc((void **) &b.count, sizeof(unsigned int)));
     unsigned int logged = 0;
-    for (int attempt = 0; attempt < 6; ++attempt) {
+    for (int attempt = 0; attempt < 12; ++attempt) {
         HIP_TRY(hipMemset(b.count, 0, sizeof(unsigned int)));
         const RayLog log{b.rays, b.count, cap, (1u << k) - 1u};
         Pending pd;
@@ -732,8 +747,10 @@ int rt_scene_tune(rt_scene *scene, const rt_camera *camera, int32_t max_w, int32
         break;
     }
     out.probe_rows = nProbe;
-    if (logged > cap) logged = cap;
-    if (logged == 0) { report(); return RT_OK; }
+    // A log that still overflows holds whichever rays happened to be appended first: a scheduling-dependent subset, from which the
+    // tree (and the box-test counters) would differ from run to run and from rank to rank.  Pixels would not, but "the same call
+    // yields the same tree" is part of the contract: such a scene is left untuned.
+    if (logged > cap || logged == 0) { report(); return RT_OK; }
     // ---- host: sort the log (its order depends on scheduling, its content does not) and rebuild ----
     std::vector<RawRay> raw(logged);
     HIP_TRY(hipMemcpy(raw.data(), b.rays, (size_t) logged * sizeof(RawRay), hipMemcpyDeviceToHost));
@@ -957,18 +974,24 @@ int rt_render_frame(const rt_scene *scene, const rt_camera *camera, int32_t max_
             rc = comms_for(devs, &comms);
             if (rc != RT_OK) return rc;
             RcclApi &nc = rccl();
+            // nothing returns between GroupStart and GroupEnd: an early return would leave RCCL in group mode for the rest of the
+            // process (the communicators are cached); errors are collected and reported after the group has been closed
             int e = nc.GroupStart();
-            for (int i = viaSelf ? 0 : 1; i < n_devices && e == 0; ++i) {
+            hipError_t he = hipSuccess;
+            for (int i = viaSelf ? 0 : 1; i < n_devices && e == 0 && he == hipSuccess; ++i) {
                 const size_t count = (size_t) fd[(size_t) i].n_rows * (size_t) cols * 4u;
                 if (count == 0) continue;
-                HIP_TRY(hipSetDevice(devices[i]));
+                he = hipSetDevice(devices[i]);
+                if (he != hipSuccess) break;
                 e = nc.Send(fd[(size_t) i].accum, count, RT_NCCL_INT32, 0, (*comms)[(size_t) i], fd[(size_t) i].stream);
                 if (e != 0) break;
-                HIP_TRY(hipSetDevice(devices[0]));
+                he = hipSetDevice(devices[0]);
+                if (he != hipSuccess) break;
                 e = nc.Recv(fd[(size_t) i].stage, count, RT_NCCL_INT32, i, (*comms)[0], fd[0].stream);
             }
             const int e2 = nc.GroupEnd();
             if (e == 0) e = e2;
+            if (he != hipSuccess) return fail(RT_ERR_HIP, std::string("RCCL gather: hipSetDevice: ") + hipGetErrorString(he));
             if (e != 0) return fail(RT_ERR_HIP, std::string("RCCL gather: ") + nc.GetErrorString(e));
             for (int i = 1; i < n_devices; ++i) { HIP_TRY(hipSetDevice(devices[i])); HIP_TRY(hipStreamSynchronize(fd[(size_t) i].stream)); }
         }

@@ -110,6 +110,27 @@ int main(void) {
     CHECK(rt_format_ppm(px, 2, 3, 0, buf, sizeof(buf)) == 62);
     CHECK(strcmp(buf, "P3\n3 2\n255\n255 0 0 0 255 0 0 0 255\n255 255 0 255 255 255 0 0 0") == 0);
     CHECK(rt_gamma_correct(64) == 128 && rt_gamma_correct(255) == 255 && rt_gamma_correct(1) == 16);
+    /* TestPpmOutput.fs:12-46 end to end: the 3x2 image spilled in ImageOutput.resume's temp-file format (ImageOutput.fs:131-161:
+     * `<row>,<col>\n` in ASCII with 0 written as NO digits, then three raw bytes), read back (readPixelMap, ImageOutput.fs:46-113),
+     * and written as P3: the reference's golden text again */
+    {
+        uint8_t map[128], back[18], present[6];
+        const int64_t len = rt_format_pixel_map(px, 2, 3, map, sizeof(map));
+        /* rows 0,1 x cols 0,1,2: "," "\n" + 3 bytes = 5 for (0,0); one digit more per non-zero coordinate */
+        CHECK(len == 5 + 6 + 6 + 6 + 7 + 7);
+        CHECK(memcmp(map, ",\n\xff\x00\x00,1\n\x00\xff\x00", 11) == 0);
+        memset(back, 7, sizeof(back));
+        CHECK(rt_parse_pixel_map(map, (size_t) len, 2, 3, back, present) == 6);
+        for (int i = 0; i < 6; ++i) CHECK(present[i] == 1);
+        CHECK(memcmp(back, px, sizeof(px)) == 0);
+        CHECK(rt_format_ppm(back, 2, 3, 0, buf, sizeof(buf)) == 62);
+        CHECK(strcmp(buf, "P3\n3 2\n255\n255 0 0 0 255 0 0 0 255\n255 255 0 255 255 255 0 0 0") == 0);
+        /* a file cut off in the middle of a pixel: the pixels before the cut are kept, nothing else is touched (ImageOutput.fs:69-106) */
+        memset(back, 7, sizeof(back));
+        CHECK(rt_parse_pixel_map(map, (size_t) len - 2, 2, 3, back, present) == 5 && present[5] == 0 && back[15] == 7);
+        /* a pixel outside the image is an error (the reference throws) */
+        CHECK(rt_parse_pixel_map(map, (size_t) len, 1, 3, back, present) == -RT_ERR_INVALID_ARGUMENT);
+    }
 
     /* render: loud failure without a GPU, a real frame with one */
     const double o0[3] = {0.0, 0.0, 0.0}, z[3] = {0.0, 0.0, 1.0};

@@ -246,8 +246,8 @@ def test_final_scene_thumbnail(orc):
 
 
 def test_textured_scenes_render_identically(orc):
-    """Checkered UV ramps and image textures through Texture.colourAt / planeMapInverse: both sides call glibc's acos,
-    atan2 and sin (CPython's math module is libm), so even these agree exactly."""
+    """Checkered UV ramps and image textures through Texture.colourAt / planeMapInverse: both sides take Math.Acos / Atan2 / Sin as
+    the correctly rounded values (the oracle through binary128, the literal restatement through mpmath), so even these agree exactly."""
     objs, cam, mw, mh = scenes.all_materials(spp=10, depth=8, pixels=6)
     got = literal_render(objs, cam, mw, mh, seed=3)
     accum, _rgb, _st = orc.OracleScene(objs).render_rows(mw, mh, cam.to_abi(), seed=3)
@@ -257,6 +257,31 @@ def test_textured_scenes_render_identically(orc):
         got = literal_render(objs, cam, mw, mh, seed=seed)
         accum, _rgb, _st = orc.OracleScene(objs).render_rows(mw, mh, cam.to_abi(), seed=seed)
         assert np.array_equal(got, accum.astype(np.int64)), seed
+
+
+def test_platform_libm_textures_informational(orc, record_property):
+    """INFORMATIONAL.  The reference calls .NET's Math.Acos / Atan2 / Sin, i.e. the platform's C runtime, which is within an ulp of
+    the correctly rounded value but not always equal to it; no reference fixture says which value a real run returns, so textures
+    are "parity unpinned" against the reference itself.  This test measures how far that could reach: the
+    literal restatement with THIS platform's libm against the oracle (correctly rounded), per-pixel sums compared.  One ulp of
+    (u, v) moves a truncating texel index or a checker decision only when the coordinate sits on the boundary, so the expected number
+    of differing pixels is zero or a handful; the count is recorded, and only an absurd one (> 2 % of the pixels) fails."""
+    import fsharp_literal as lit
+    total = differing = 0
+    lit.PLATFORM_LIBM = True
+    try:
+        cases = [scenes.all_materials(spp=10, depth=8, pixels=6) + (3,)] + [scenes.random_scene(500 + s, pixels=5) + (s,) for s in range(6)]
+        for objs, cam, mw, mh, seed in cases:
+            got = literal_render(objs, cam, mw, mh, seed=seed)
+            accum, _rgb, _st = orc.OracleScene(objs).render_rows(mw, mh, cam.to_abi(), seed=seed)
+            total += got.shape[0] * got.shape[1] if got.ndim == 3 else len(got)
+            differing += int(np.any(got.reshape(-1, 4) != accum.astype(np.int64).reshape(-1, 4), axis=1).sum())
+    finally:
+        lit.PLATFORM_LIBM = False
+    record_property("pixels", total)
+    record_property("pixels_differing_with_platform_libm", differing)
+    print(f"platform libm instead of correctly rounded trig: {differing} of {total} pixels differ")
+    assert differing <= max(1, total // 50)
 
 
 def test_camera_make_basic(orc):
