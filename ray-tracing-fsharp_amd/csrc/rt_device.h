@@ -601,6 +601,72 @@ RTD_INLINE void leaf_test_object(const SceneView<LDS> &sc, V3 o, V3 d, WalkCtx &
     const double a = t * t;
     if (a < c.bestF || (a == c.bestF && prim < w.best)) { c.bestF = a; w.best = prim; w.bestLen = t; }
 }
+// The same filter loop over the image in GLOBAL memory (scenes that do not fit the LDS): `off` is the record's byte offset from the
+// node32 section (the links as the host stored them), the four reads are global_load with a scalar base.  A trip waits for L2 (or L1)
+// instead of LDS, so its ~25 VALU instructions are not what it costs; the queue of pending leaves is two FULL-WIDTH entries
+// (pend0 the older, pend1 the newer; an entry is the record's third link word, RTD_PEND_MARK | object for scenes of < 16384 objects,
+// RTD_PEND_WIDE | object beyond) because such scenes may have millions of objects.
+#define RTD_PEND_WIDE 0x80000000u
+RTD_INLINE int node_loop_glb32(int off, uint32_t &pend0, uint32_t &pend1, const unsigned char *base, int end, int stop, const WalkCtx32 &c) {
+    int ax, ay, az, cnt;
+    unsigned long long save, save2;
+    asm volatile(
+        "s_waitcnt vmcnt(0)\n"
+        "1:\n"
+        "  v_cmp_gt_i32 vcc, %[end], %[off]\n"
+        "  v_cmp_eq_u32 %[save2], 0, %[pend1]\n"
+        "  s_and_b64 vcc, vcc, %[save2]\n"
+        "  s_bcnt1_i32_b64 %[cnt], vcc\n"
+        "  s_cmp_le_u32 %[cnt], %[stop]\n"
+        "  s_cbranch_scc1 2f\n"
+        "  s_and_saveexec_b64 %[save], vcc\n"
+        "  v_add_u32 %[ax], %[off], %[nx]\n"
+        "  v_add_u32 %[ay], %[off], %[ny]\n"
+        "  v_add_u32 %[az], %[off], %[nz]\n"
+        "  global_load_dwordx2 v[100:101], %[ax], %[base]\n"
+        "  global_load_dwordx2 v[102:103], %[ay], %[base] offset:16\n"
+        "  global_load_dwordx2 v[104:105], %[az], %[base] offset:32\n"
+        "  global_load_dwordx4 v[106:109], %[off], %[base] offset:48\n"
+        "  s_waitcnt vmcnt(3)\n"
+        "  v_fma_f32 v100, v100, %[ix], %[cnx]\n"
+        "  v_fma_f32 v101, v101, %[ix], %[cfx]\n"
+        "  s_waitcnt vmcnt(2)\n"
+        "  v_fma_f32 v102, v102, %[iy], %[cny]\n"
+        "  v_fma_f32 v103, v103, %[iy], %[cfy]\n"
+        "  s_waitcnt vmcnt(1)\n"
+        "  v_fma_f32 v104, v104, %[iz], %[cnz]\n"
+        "  v_fma_f32 v105, v105, %[iz], %[cfz]\n"
+        "  v_max3_f32 v100, v100, v102, v104\n"
+        "  v_min3_f32 v101, v101, v103, v105\n"
+        "  v_max_f32 v100, 0, v100\n"
+        "  v_cmp_nlt_f32 vcc, v101, v100\n"
+        "  s_waitcnt vmcnt(0)\n"
+        "  v_cndmask_b32 %[off], v107, v106, vcc\n"
+        "  v_cndmask_b32 v108, 0, v108, vcc\n"           /* the entry of a hit Leaf, else 0 */
+        "  v_cmp_ne_u32 %[save2], 0, v108\n"
+        "  v_cmp_eq_u32 vcc, 0, %[pend0]\n"
+        "  s_and_b64 vcc, %[save2], vcc\n"               /* into the empty older slot */
+        "  v_cndmask_b32 %[pend0], %[pend0], v108, vcc\n"
+        "  s_andn2_b64 vcc, %[save2], vcc\n"             /* or into the newer one */
+        "  v_cndmask_b32 %[pend1], %[pend1], v108, vcc\n"
+        "  s_mov_b64 exec, %[save]\n"
+        "  s_branch 1b\n"
+        "2:\n"
+        : [off] "+v"(off), [pend0] "+v"(pend0), [pend1] "+v"(pend1), [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [cnt] "=&s"(cnt), [save] "=&s"(save),
+          [save2] "=&s"(save2)
+        : [end] "s"(end), [stop] "s"(stop), [base] "s"(base), [nx] "v"(c.nX), [ny] "v"(c.nY), [nz] "v"(c.nZ), [ix] "v"(c.ix), [iy] "v"(c.iy), [iz] "v"(c.iz),
+          [cnx] "v"(c.cnx), [cny] "v"(c.cny), [cnz] "v"(c.cnz), [cfx] "v"(c.cfx), [cfy] "v"(c.cfy), [cfz] "v"(c.cfz)
+        : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109");
+    return off;
+}
+// the oldest entry of that queue, removed from it
+RTD_INLINE int pend_pop_wide(uint32_t &pend0, uint32_t &pend1) {
+    const uint32_t e = pend0;
+    pend0 = pend1;
+    pend1 = 0u;
+    return (int) ((e & RTD_PEND_WIDE) ? (e & ~RTD_PEND_WIDE) : (e & (RTD_PEND_MARK - 1u)));
+}
+
 // A leaf the single-precision filter let through (node_loop_lds32).  The reference tests the sphere iff the ray hits the leaf's own
 // box (Scene.fs:41), so a sphere hit found here counts only if BoundingBox.hits(leaf box) holds -- exactly.  That test is IMPLIED by
 // the sphere hit itself in all but a sliver of cases, and is evaluated only in that sliver:

@@ -117,6 +117,18 @@ template <> RTD_INLINE SceneView<true> make_view<true, true>(const RenderParams 
     v.tex = p.tex; v.texels = p.texels;
     return v;
 }
+template <> RTD_INLINE SceneView<false> make_view<false, true>(const RenderParams &p, const unsigned char *) { // the timed variant over global memory
+    SceneView<false> v;
+    const unsigned char *b = p.scene_image;
+    v.node = b + p.off.node32; // links are byte offsets from here (node_loop_glb32)
+    v.geo = (const d2 *) (b + p.off.geo);
+    v.meta = (const i2 *) (b + p.off.meta);
+    v.mat = (const double *) (b + p.off.mat);
+    v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
+    v.first = 0; v.end = v.n_nodes * RTD_NODE32_BYTES;
+    v.tex = p.tex; v.texels = p.texels;
+    return v;
+}
 template <> RTD_INLINE SceneView<false> make_view<false, false>(const RenderParams &p, const unsigned char *) {
     SceneView<false> v;
     const unsigned char *b = p.scene_image;
@@ -185,10 +197,13 @@ struct Sched {
     Rng rng;
     uint32_t colour, slotOff;
     int bounces;
-    uint32_t pend; // queue of pending leaf tests (node_loop_lds); always 0 outside a walk and in the variants that do not queue
+    uint32_t pend; // queue of pending leaf tests (node_loop_lds32: two 16-bit entries; node_loop_glb32: the older full-width entry); always 0
+                   // outside a walk and in the counting variant, which does not queue
     uint32_t texc; // L_SLOW lanes: the hit's texture colour if stage_tex has evaluated one, else RTD_NO_TEX
     // set by the stages for the caller's bookkeeping: this lane's path ended during the current turn, with this colour
     bool ended;
+    uint32_t pend1; // node_loop_glb32's newer entry (declared apart from `pend`: as neighbours the two are stored together by one vector
+                    // store, and the whole scheduler state then lives in scratch memory)
     uint32_t result;
 
     RTD_INLINE Sched(const RenderParams &p_, const SceneView<LDS> &sc_, Counters &cnt_, StageStats &ss_, unsigned char *pool_, RTD_AS3 unsigned char *poolLds_)
@@ -197,7 +212,7 @@ struct Sched {
         o = mk(0, 0, 0); d = mk(0, 0, 0);
         walk_begin(w, sc.first); w.off = end; // idle lanes are parked at `end`
         rng.x = rng.y = rng.z = rng.w = 0;
-        colour = 0; slotOff = 0; bounces = 0; pend = 0u; texc = RTD_NO_TEX;
+        colour = 0; slotOff = 0; bounces = 0; pend = 0u; pend1 = 0u; texc = RTD_NO_TEX;
         ended = false; result = 0;
     }
 
@@ -297,13 +312,16 @@ struct Sched {
     }
     // the idle lane of rank `rank` takes its parked path, if the plan gives it one
     RTD_INLINE bool unpark_lane(uint32_t rank, uint32_t nUnL, uint32_t nUnA, uint32_t nUnT) {
+        // (the three counters are read HERE, unconditionally: read inside the branches, the optimiser merges the loads into one load
+        // from a selected address, and the scheduler's state then lives in scratch memory instead of registers)
+        const uint32_t topL = parkedL - 1u, topA = parked - 1u, topT = parkedT - 1u;
         if (rank < nUnL) {
-            if (p.park_l_lds) park_load_lds((uint32_t) p.park_l, parkedL - 1u - rank);
-            else park_load(pool_l(), (uint32_t) p.park_l, parkedL - 1u - rank, L_LAMB);
+            if (p.park_l_lds) park_load_lds((uint32_t) p.park_l, topL - rank);
+            else park_load(pool_l(), (uint32_t) p.park_l, topL - rank, L_LAMB);
             return true;
         }
-        if (rank < nUnL + nUnA) { park_load(pool, (uint32_t) p.park, parked - 1u - (rank - nUnL), L_SLOW); texc = RTD_NO_TEX; return true; }
-        if (TEX && rank < nUnL + nUnA + nUnT) { park_load(pool_t(), (uint32_t) p.park, parkedT - 1u - (rank - nUnL - nUnA), L_TEX); return true; }
+        if (rank < nUnL + nUnA) { park_load(pool, (uint32_t) p.park, topA - (rank - nUnL), L_SLOW); texc = RTD_NO_TEX; return true; }
+        if (TEX && rank < nUnL + nUnA + nUnT) { park_load(pool_t(), (uint32_t) p.park, topT - (rank - nUnL - nUnA), L_TEX); return true; }
         return false;
     }
 
@@ -367,20 +385,27 @@ struct Sched {
         if (__builtin_amdgcn_ballot_w64(st == L_WALK) == 0ull) return;
         const int nBusy = __popcll(__builtin_amdgcn_ballot_w64(st != L_IDLE));
         const int stop = (nBusy - p.yield_lanes) > 0 ? (nBusy - p.yield_lanes) : 0; // active <= stop  <=>  waiting >= yield
-        if constexpr (LDS && !COUNT) {
-            // the timed variant: the hand-written single-precision filter loop with its queue of pending leaves (rt_device.h); the
-            // leaf pass makes the leaf's exact box test and then the sphere's; a lane is finished when its walk is exhausted AND
-            // its queue is empty
+        if constexpr (!COUNT) {
+            // the timed variant: the hand-written single-precision filter loop with its queue of pending leaves (rt_device.h) over the
+            // LDS copy of the scene, or over global memory for a scene that does not fit; the leaf pass makes the sphere test and,
+            // where the hit does not imply it, the leaf's exact box test; a lane is finished when its walk is exhausted AND its
+            // queue is empty
             const WalkCtx32 f = walk_ctx32(o, d, p.off.bmax);
             double bestF = (w.best < 0) ? __builtin_inf() : w.bestLen * w.bestLen; // `a = point * point` (Scene.fs:45), recomputed
             const bool implied = p.off.box_implied != 0; // (rays of this kernel are unitised: Ray.make')
             if (RTD_CLK) ss.trips++; // (diagnostic build: walk-stage entries and leaf passes; the loop's trips are not counted)
             for (;;) {
                 const unsigned long long k0 = RTD_CLK ? __builtin_amdgcn_s_memtime() : 0ull;
-                w.off = node_loop_lds32(w.off, pend, end, stop, f);
+                if constexpr (LDS) w.off = node_loop_lds32(w.off, pend, end, stop, f);
+                else w.off = node_loop_glb32(w.off, pend, pend1, (const unsigned char *) sc.node, end, stop, f);
                 const unsigned long long k1 = RTD_CLK ? __builtin_amdgcn_s_memtime() : 0ull;
                 if (RTD_CLK && __builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) ss.leaf++;
-                if (pend != 0u) leaf_test_object_exact<LDS>(sc, o, d, bestF, w, pend_pop(pend), implied);
+                if (pend != 0u) {
+                    int prim;
+                    if constexpr (LDS) prim = pend_pop(pend);
+                    else prim = pend_pop_wide(pend, pend1);
+                    leaf_test_object_exact<LDS>(sc, o, d, bestF, w, prim, implied);
+                }
                 if (RTD_CLK) { ss.tLoop += k1 - k0; ss.tLeaf += __builtin_amdgcn_s_memtime() - k1; }
                 const bool fin = (st == L_WALK) && (w.off >= end) && pend == 0u;
                 if (fin) st = L_DONE;
@@ -745,7 +770,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
 
     const uint32_t sceneBytes = LDS ? stage_scene<BLOCK, !COUNT>(p, smem) : 0u;
-    const SceneView<LDS> sc = make_view<LDS, LDS && !COUNT>(p, smem);
+    const SceneView<LDS> sc = make_view<LDS, !COUNT>(p, smem);
     const uint32_t P = (uint32_t) p.chunk;
     RTD_AS3 uint32_t *wv = (RTD_AS3 uint32_t *) (smem + sceneBytes) + (size_t) wave * (MODE == 1 ? RTD_WAVE_WORDS_A(P) : RTD_WAVE_WORDS(P));
     RTD_AS3 uint32_t *acc = wv;

@@ -523,7 +523,8 @@ static void encode_image(HostScene &s) {
         const int32_t onMiss32 = wt.skip[i] * RTD_NODE32_BYTES;
         lk32[0] = leaf ? onMiss32 : (int32_t) ((i + 1) * RTD_NODE32_BYTES);
         lk32[1] = onMiss32;
-        lk32[2] = leaf ? (int32_t) (RTD_PEND_MARK | (uint32_t) wt.prim[i]) : 0;
+        // the queue entry: 16 bits for scenes the LDS loop may walk (< 16384 objects), full width beyond (global loop only)
+        lk32[2] = !leaf ? 0 : (nobj < 16384u ? (int32_t) (RTD_PEND_MARK | (uint32_t) wt.prim[i]) : (int32_t) (RTD_PEND_WIDE | (uint32_t) wt.prim[i]));
         lk32[3] = leaf ? 16 : 0;
     }
     off.bmax = bmax;

@@ -173,8 +173,10 @@ def movedCamera():  # SampleImages.fs:702-810 (the negative-radius sphere is BOU
     return (objs, camera) + _extent(aspect, 300)
 
 
-def randomSpheres(seed: int = 2024, spp: int = 500, pixels: int = 800):
+def randomSpheres(seed: int = 2024, spp: int = 500, pixels: int = 800, grid: int = 11):
     """SampleImages.randomSpheres (SampleImages.fs:812-960), the RTIOW final scene = BASELINE config 3.
+    `grid` is the reference's literal 11 (cells a, b in [-11, 10]); larger values give the same recipe over more cells -- scenes of
+    ~4 * grid^2 spheres for the scene-size measurements (scripts/scene_sizes.py), never a BASELINE config.
 
     Draw order from the single scene stream, per grid cell (a, b) in the reference's loop order:
       materialChoice; centre.x offset; centre.z offset; then (if the cell is kept)
@@ -195,8 +197,8 @@ def randomSpheres(seed: int = 2024, spp: int = 500, pixels: int = 800):
         return not (abs(a - b) < TOLERANCE) and a < b
 
     objs: List[Hittable] = []
-    for a in range(-11, 11):
-        for b in range(-11, 11):
+    for a in range(-grid, grid):
+        for b in range(-grid, grid):
             materialChoice = rnd.Get()
             centre = Point.make(float(a) + 0.9 * rnd.Get(), 0.2, float(b) + 0.9 * rnd.Get())
             d = Point.differenceToThenFrom(centre, Point.make(4.0, 0.2, 0.0))
