@@ -7,7 +7,7 @@ mkdir -p "$OUT"
 for lib in "$@"; do
     name=$(basename "$lib" .so)
     if [ "$lib" = default ]; then unset RTFS_LIB; else export RTFS_LIB="$PWD/$lib"; fi
-    python bench.py --steps 10 --warmup 2 --cpu-seconds 0 ${AB_FLAGS:-} > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err" || echo "bench $name failed"
+    python bench.py --steps 10 --warmup 2 --cpu-seconds 0 --no-untuned-leg ${AB_FLAGS:-} > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err" || echo "bench $name failed"
     python scripts/one_frame.py --stage-stats > "$OUT/stages_$name.txt" 2>&1 || echo "stages $name failed"
     python - "$OUT/bench_$name.json" "$name" <<'PY'
 import json, sys
