@@ -186,9 +186,10 @@ int rt_scene_get_walk_tree(const rt_scene *scene, int32_t *skip, int32_t *prim, 
  * A scene that walks the reference's own tree (RT_WALK_TREE_REFERENCE, or fewer than 3 bounded spheres, or non-finite boxes)
  * is left alone: tuned = 0.  Must not run concurrently with renders of the same scene: it replaces the device images (after
  * waiting for the devices that hold one).  Typical use: once after rt_scene_create, with the camera and image size of the
- * frames to come.  Cost on the final scene: ~8 ms of GPU time for the probe + ~12 ms of host time for the build, against ~22 ms
- * saved per 2401x1601x500spp frame (0.4 s per 7681x4321x1000spp frame): it pays from the second frame of a scene on, or on the
- * first if that one takes more than about 0.15 s. */
+ * frames to come.  Cost on the final scene (round 3): ~1.3 ms of GPU time for the probe (16 rows at a reduced sample count, the
+ * timed kernel variant) + ~4 ms of host time for the build (subtrees on separate threads), ~6.5 ms wall in all, against ~13 ms
+ * saved per 2401x1601x500spp frame: it pays on the FIRST frame of such a scene (123 ms against 130 ms untuned, 116.6 ms from the
+ * second frame on; bench.py reports all three). */
 typedef struct rt_tune_info {
     uint32_t struct_size;      /* sizeof(rt_tune_info) as the caller compiled it */
     int32_t  tuned;            /* 1: the walk tree was replaced */

@@ -63,7 +63,7 @@ struct RenderParams {
     unsigned int *live_count;      // number of pairs / list entries (device side)
     unsigned long long *queue_b;   // next unassigned list entry
     uint32_t total_waves;          // waves of the grid (guided unit sizes in pass B)
-    // rt_scene_tune's probe (counting variant only): every ray whose stream-state hash has `ray_log_mask` clear is appended
+    // rt_scene_tune's probe: every ray whose stream-state hash has `ray_log_mask` clear is appended
     double *ray_log;               // [ray_log_cap][6]: origin, direction; null outside a probe
     unsigned int *ray_log_count;   // rays that wanted a slot (may exceed the capacity: the probe is then repeated more thinly)
     uint32_t ray_log_cap, ray_log_mask;
@@ -219,7 +219,8 @@ struct Sched {
     // the probe of rt_scene_tune: a thinned-out log of the rays as they start (which rays: a hash of the ray's stream state, so
     // the logged SET does not depend on scheduling; the host sorts it)
     RTD_INLINE void log_ray() {
-        if (p.ray_log != nullptr && ((((rng.x ^ rng.w) * 0x9E3779B1u) >> 8) & p.ray_log_mask) == 0u) {
+        if (p.ray_log == nullptr) return; // wave-uniform: one scalar compare per ray outside a probe
+        if (((((rng.x ^ rng.w) * 0x9E3779B1u) >> 8) & p.ray_log_mask) == 0u) {
             const unsigned int at = atomicAdd(p.ray_log_count, 1u);
             if (at < p.ray_log_cap) {
                 double *r = p.ray_log + 6u * (size_t) at;
@@ -241,7 +242,8 @@ struct Sched {
         if (camera_ray(*cp, row, col, rng, o, d)) {
             st = L_WALK;
             walk_begin(w, sc.first);
-            if (COUNT) { cnt.rays++; log_ray(); }
+            if (COUNT) cnt.rays++;
+            log_ray();
             return true;
         }
         return false; // Scene.fs:144's ValueOption.get would throw; the sample counts as Black (adds nothing)
@@ -337,7 +339,8 @@ struct Sched {
         else {
             st = L_WALK;
             walk_begin(w, sc.first);
-            if (COUNT) { cnt.rays++; log_ray(); }
+            if (COUNT) cnt.rays++;
+            log_ray();
         }
     }
 

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -147,7 +148,8 @@ class SahBuilder {
     std::vector<uint32_t> cntP, cntS;
     static const size_t kSweepMax = 4096; // above this a node is split on 32 centroid bins per axis instead of a full sweep
     static const size_t kProbeMin = 32;   // fewer probe rays than this in a box: its subtree is split by area
-    static const size_t kSweepRays = 512; // rays a sweep looks at, at most (about)
+    static const size_t kSweepRays = 128; // rays a sweep looks at, at most (about): the split costs need a few percent only (final scene, box tests
+                                          // per held-out ray after thinning: 18.08 with 512, 18.15 with 256, 18.17 with 128, 18.27 with 64; time ~linear)
     double centroid2(int32_t id, int axis) const { return ob[(size_t) id].mn[axis] + ob[(size_t) id].mx[axis]; }
     void sort_axis(int32_t *ids, size_t n, int axis) const {
         std::sort(ids, ids + n, [&](int32_t a, int32_t b) {
@@ -260,10 +262,33 @@ class SahBuilder {
                      return ca < cb || (ca == cb && a < b);
                  });
             const double myArea = half_area(all);
-            go(ids, k, depth + 1, hidx, myHits, myArea);
-            go(ids + k, n - k, depth + 1, hidx, myHits, myArea);
+            if (rays && depth <= kParallelDepth && n >= kParallelMin) {
+                // the two subtrees are independent: the left one on another thread into a tree of its own, appended in pre-order
+                // afterwards -- the same tree, node for node, as the sequential build (rt_scene_tune's host time: 11.5 -> ~3 ms)
+                FlatTree left, right;
+                auto fut = std::async(std::launch::async, [&]() { SahBuilder b(ob, left, rays); b.suffix.resize(ob.size() + 1); b.go(ids, k, depth + 1, hidx, myHits, myArea); });
+                { SahBuilder b(ob, right, rays); b.suffix.resize(ob.size() + 1); b.go(ids + k, n - k, depth + 1, hidx, myHits, myArea); }
+                fut.get();
+                append(left);
+                append(right);
+            } else {
+                go(ids, k, depth + 1, hidx, myHits, myArea);
+                go(ids + k, n - k, depth + 1, hidx, myHits, myArea);
+            }
         }
         t.skip[me] = (int32_t) t.skip.size();
+    }
+    static const int kParallelDepth = 3;     // up to 8 subtrees in flight
+    static const size_t kParallelMin = 48;   // leaves below which a subtree is not worth a thread
+    void append(const FlatTree &sub) {
+        const int32_t base = (int32_t) t.skip.size();
+        for (size_t i = 0; i < sub.skip.size(); ++i) {
+            t.skip.push_back(sub.skip[i] + base);
+            t.prim.push_back(sub.prim[i]);
+            t.box.push_back(sub.box[i]);
+        }
+        t.hits.insert(t.hits.end(), sub.hits.begin(), sub.hits.end());
+        if (sub.depth > t.depth) t.depth = sub.depth;
     }
 };
 

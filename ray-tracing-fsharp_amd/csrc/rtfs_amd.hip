@@ -716,32 +716,46 @@ int rt_scene_tune(rt_scene *scene, const rt_camera *camera, int32_t max_w, int32
     rc = guard.enter(device);
     if (rc != RT_OK) return rc;
 
-    // ---- the probe: 16 rows spread over the frame, rays logged 1 in 2^k ----
+    // ---- the probe: 16 rows spread over the frame at a reduced sample count (a few million rays), traced by the TIMED kernel
+    // variant, rays logged 1 in 2^k ----
     const int rows = 2 * max_h + 1, cols = 2 * max_w + 1;
     const int nProbe = rows < 16 ? rows : 16, stride = rows / nProbe, first = stride / 2;
-    const uint32_t cap = 1u << 18, want = 8192u;
-    const double upper = (double) nProbe * (double) cols * (double) camera->samples_per_pixel * 4.0; // ~4 rays per sample
+    const uint32_t cap = 1u << 15, want = 8192u;
+    rt_camera probeCam = *camera;
+    {
+        const double perSample = (double) nProbe * (double) cols * 3.3; // rays one sample of every probe pixel brings
+        int spp = (int) std::ceil(4.0e6 / perSample);
+        if (spp < 48) spp = 48; // well past the 2k+1 = 11 samples every pixel gets: the pixels that go on (Scene.fs:185-192) must weigh in the
+                                // probe as they do in the frame, or the tree is tuned for the sky's rays
+        if (spp < camera->samples_per_pixel) probeCam.samples_per_pixel = spp;
+    }
+    const double upper = (double) nProbe * (double) cols * (double) probeCam.samples_per_pixel * 4.0; // ~4 rays per sample
     int k = 0;
     while (k < 20 && upper / (double) (1u << k) > (double) (cap / 2u)) ++k;
     struct Bufs {
-        int32_t *accum = nullptr; double *rays = nullptr; unsigned int *count = nullptr;
-        ~Bufs() { (void) hipFree(accum); (void) hipFree(rays); (void) hipFree(count); }
+        unsigned char *all = nullptr;
+        ~Bufs() { (void) hipFree(all); }
     } b;
-    HIP_TRY(hipMalloc((void **) &b.accum, (size_t) nProbe * (size_t) cols * 16u));
-    HIP_TRY(hipMalloc((void **) &b.rays, (size_t) cap * 48u));
-    HIP_TRY(hipMalloc((void **) &b.count, sizeof(unsigned int)));
+    const size_t accumBytes = ((size_t) nProbe * (size_t) cols * 16u + 255u) & ~(size_t) 255u, rayBytes = (size_t) cap * 48u;
+    HIP_TRY(hipMalloc((void **) &b.all, accumBytes + rayBytes + 256u));
+    int32_t *pAccum = (int32_t *) b.all;
+    double *pRays = (double *) (b.all + accumBytes);
+    unsigned int *pCount = (unsigned int *) (b.all + accumBytes + rayBytes);
     unsigned int logged = 0;
     for (int attempt = 0; attempt < 12; ++attempt) {
-        HIP_TRY(hipMemset(b.count, 0, sizeof(unsigned int)));
-        const RayLog log{b.rays, b.count, cap, (1u << k) - 1u};
+        HIP_TRY(hipMemsetAsync(pCount, 0, sizeof(unsigned int), nullptr));
+        const RayLog log{pRays, pCount, cap, (1u << k) - 1u};
         Pending pd;
-        rc = launch_render(scene, camera, max_w, max_h, seed, device, first, stride, nProbe, RT_RENDER_COUNTERS, b.accum, nullptr, nullptr, nullptr, true, pd, &log);
+        rt_render_options po{};
+        po.struct_size = (uint32_t) sizeof(po);
+        po.chunk_pixels = 4; // 16 rows are a few thousand pixels for 4096 waves: small units, or most waves get none and a few get the long ones
+        rc = launch_render(scene, &probeCam, max_w, max_h, seed, device, first, stride, nProbe, 0u, pAccum, nullptr, nullptr, &po, true, pd, &log);
         if (rc != RT_OK) return rc;
         rt_stats st;
         rc = collect_stats(pd, &st);
         if (rc != RT_OK) return rc;
         out.probe_ms += st.kernel_ms;
-        HIP_TRY(hipMemcpy(&logged, b.count, sizeof(logged), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&logged, pCount, sizeof(logged), hipMemcpyDeviceToHost));
         if (logged > cap && k < 20) { k += 2; continue; }           // too many: log more thinly
         if (logged < want / 8u && k > 0) { k = k > 3 ? k - 3 : 0; continue; } // too few: log more densely
         break;
@@ -753,7 +767,7 @@ int rt_scene_tune(rt_scene *scene, const rt_camera *camera, int32_t max_w, int32
     if (logged > cap || logged == 0) { report(); return RT_OK; }
     // ---- host: sort the log (its order depends on scheduling, its content does not) and rebuild ----
     std::vector<RawRay> raw(logged);
-    HIP_TRY(hipMemcpy(raw.data(), b.rays, (size_t) logged * sizeof(RawRay), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(raw.data(), pRays, (size_t) logged * sizeof(RawRay), hipMemcpyDeviceToHost));
     std::sort(raw.begin(), raw.end(), [](const RawRay &x, const RawRay &y) { return memcmp(&x, &y, sizeof(RawRay)) < 0; });
     rc = apply_tune(scene, raw, out);
     if (rc == RT_OK) report();
