@@ -361,6 +361,14 @@ int rt_dev_bbox_hits(int32_t device, int32_t n, const double *rays, const double
  * compiled C++.  Boxes are rounded outward to single precision as the scene image does; bmax (>= 0) enlarges the margin's scale
  * beyond the batch's largest |coordinate| (the scene image uses the largest |coordinate| of its tree). */
 int rt_dev_bbox_filter(int32_t device, int32_t n, const double *rays, const double *boxes, double bmax, int32_t *out);
+/* The timed kernel walks the tree ONCE per pixel for all of the pixel's camera rays (Scene.traceOnce, Scene.fs:129-144): with the
+ * pyramid from the eye through the pixel's patch of the viewport it collects the Leaves any of those rays can reach (at most four;
+ * csrc/rt_device.h, pixel_candidates), and a camera ray then starts with those Leaves queued for their exact tests instead of
+ * walking.  This hook returns that set for n pixels given as (row, col) pairs in the reference's coordinates (row = maxH - r - 1,
+ * col = c - maxW, Scene.fs:219,226): leaves_out[i*4 .. i*4+3] = hittable indices (input order of rt_scene_create), -1 padded;
+ * leaves_out[i*4] = -2 when the pixel's camera rays walk the tree as all other rays do (more than four Leaves in reach). */
+int rt_dev_pixel_candidates(int32_t device, const rt_scene *scene, const rt_camera *camera, int32_t max_width_coord, int32_t max_height_coord,
+                            int32_t n, const int32_t *row_col, int32_t *leaves_out);
 /* Sphere.firstIntersection (Sphere.fs:349-386). spheres: n*4 (centre xyz, radius). t_out = NaN when ValueNone. */
 int rt_dev_sphere_first_intersection(int32_t device, int32_t n, const double *rays, const double *spheres, double *t_out);
 /* InfinitePlane.intersection (InfinitePlane.fs:125-136). planes: n*6 (point, unit normal). */

@@ -93,6 +93,7 @@ SIGNATURES = {
     "rt_dev_stream_state": (C.c_int, [C.c_int32, C.c_uint64, C.c_int32, _u64p, _u32p, _u32p]),
     "rt_dev_bbox_hits": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _i32p]),
     "rt_dev_bbox_filter": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, C.c_double, _i32p]),
+    "rt_dev_pixel_candidates": (C.c_int, [C.c_int32, C.c_void_p, _P(A.rt_camera), C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p]),
     "rt_dev_sphere_first_intersection": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "rt_dev_plane_intersection": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "rt_dev_pixel_combine": (C.c_int, [C.c_int32, C.c_int32, _u8p, _u8p, _u8p]),

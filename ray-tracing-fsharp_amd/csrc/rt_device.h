@@ -1046,6 +1046,90 @@ RTD_INLINE bool camera_ray(const CameraParams &cam, int row, int col, Rng &rng, 
     return unitise(vsub(end, o), d);
 }
 
+// ---- the leaves a pixel's camera rays can reach, found ONCE per pixel -----------------------------------------------------------
+// Every sample of a pixel starts with a ray from the eye through the pixel's patch of the viewport (Scene.fs:129-144: the patch is
+// the parallelogram {xo + lx * xd + ly * yd : lx in [col, col+1] * vw / maxW, ly in [row, row+1] * vh / maxH}), and with hundreds of
+// samples per pixel those rays -- a third of all rays of the bench frame -- walk the tree to the same few leaves again and again.
+// pixel_candidates walks the tree ONCE with the whole pyramid of the pixel's rays (apex at the eye, through the patch's four corners)
+// and returns the Leaves whose boxes the pyramid can touch, as the node loop's queue word (rt_device.h, node_loop_lds32); a camera
+// ray of that pixel then starts with its tree walk already exhausted and those Leaves in its queue, and the leaf pass makes each
+// Leaf's exact BoundingBox.hits (or knows it implied) and sphere test as for any other queued Leaf.  The result is the reference's:
+// a sphere is tested iff its Leaf box is hit by the ray, exactly -- the candidates only have to CONTAIN every Leaf the ray's exact
+// test could accept.  They do: box and pyramid are convex, so if all of the box lies strictly outside one of the pyramid's four side
+// planes (or behind the eye), no ray of the pixel meets it; the test below rejects a box only then.  The planes are set up in double
+// precision (rounding ~1e-12 relative: the cross products cancel to ~1e-4 of their operands for a 2401-pixel-wide image) and then
+// held, like the box's centre and half extents, in single precision; the per-box test runs in single precision with a margin of
+// 2^-18 of its terms' magnitudes (every operand carries 2^-24, the sums a few times that; a ray that the exact slab test accepts
+// misses the box by at most a few double-precision ulps of its coordinates).  The box tested is the node32 record's (rounded
+// outward: larger).  More than FOUR reachable Leaves, a degenerate pyramid, or a kernel variant without the queue: RTD_CAND_WALK,
+// and the pixel's camera rays walk the tree as all others.
+// The counting kernel variant never uses candidates, and every render test compares the two variants and the oracle.
+#define RTD_CAND_WALK 0xFFFFFFFFu
+struct F3 { float x, y, z; };
+RTD_INLINE V3 cross3(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RTD_INLINE F3 to_f3(V3 v) { F3 r; r.x = (float) v.x; r.y = (float) v.y; r.z = (float) v.z; return r; }
+// the whole box (centre c relative to the eye, half extents h >= 0) lies on the negative side of the plane n . x = 0.  Single
+// precision: n, c, h carry 2^-24 relative rounding each, the sums a few more; the margin is 2^-18 of the terms' magnitudes.
+RTD_INLINE bool outside_plane(F3 n, F3 c, F3 h) {
+    const float ax = __builtin_fabsf(n.x), ay = __builtin_fabsf(n.y), az = __builtin_fabsf(n.z);
+    const float s = ((n.x * c.x + n.y * c.y) + n.z * c.z) + ((ax * h.x + ay * h.y) + az * h.z);
+    const float m = 0x1p-18f * ((ax * (__builtin_fabsf(c.x) + h.x) + ay * (__builtin_fabsf(c.y) + h.y)) + az * (__builtin_fabsf(c.z) + h.z));
+    return s < -m; // (a NaN anywhere compares false: not rejected)
+}
+// Returns up to four reachable Leaves as two queue words (the older pair in `first`), RTD_CAND_WALK in `first` for "walk the tree".
+template <bool LDS, bool USE> RTD_INLINE uint32_t pixel_candidates(const SceneView<LDS> &sc, const CameraParams &cam, int row, int col, uint32_t &second) {
+  second = 0u;
+  if constexpr (!(LDS && USE)) return RTD_CAND_WALK; // only the timed LDS variant has the queue the candidates go into
+  else {
+    const V3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
+    F3 n[4], gcf;
+    {   // the pyramid's planes, set up in double precision (the cross products cancel to ~1e-4 of their operands) and kept in single
+        const V3 xo = mk(cam.xo[0], cam.xo[1], cam.xo[2]), xd = mk(cam.xd[0], cam.xd[1], cam.xd[2]), yd = mk(cam.yd[0], cam.yd[1], cam.yd[2]);
+        V3 g[4]; // corners (lx0,ly0) (lx1,ly0) (lx1,ly1) (lx0,ly1) of the patch, from the eye: camera_ray's arithmetic with r1, r2 in {0, 1}
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int jx = (q == 1 || q == 2) ? 1 : 0, jy = q >> 1;
+            const double lx = (((double) col + (double) jx) * cam.vw) / (double) cam.max_w;
+            const double ly = (((double) row + (double) jy) * cam.vh) / (double) cam.max_h;
+            g[q] = vsub(walk(walk(xo, xd, lx), yd, ly), eye);
+        }
+        const V3 gc = mk((g[0].x + g[1].x) + (g[2].x + g[3].x), (g[0].y + g[1].y) + (g[2].y + g[3].y), (g[0].z + g[1].z) + (g[2].z + g[3].z));
+        gcf = to_f3(gc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            V3 nq = cross3(g[q], g[(q + 1) & 3]);
+            const double sgn = dot(nq, gc);
+            if (!(sgn != 0.0)) return RTD_CAND_WALK; // degenerate pyramid (or NaN): no claim
+            // normalised to ~1 before rounding to single (|n| ~ 1e-2 |g|^2 otherwise: no under- or overflow for any camera)
+            const double sc1 = (sgn < 0.0 ? -1.0 : 1.0) / (fabs(nq.x) + fabs(nq.y) + fabs(nq.z));
+            n[q] = to_f3(vscale(sc1, nq));
+        }
+    }
+    uint32_t pend = 0u;
+    int count = 0;
+    for (int off = sc.first; off < sc.end;) {
+        const typename Ptrs<LDS>::bp rec = node_at<LDS>(sc, off);
+        const RTD_AS3 float *f = (const RTD_AS3 float *) rec;
+        const i4 lk = *(const RTD_AS3 i4 *) (rec + 48); // on_hit, on_miss, queue entry (0 for a Branch), shift
+        const float lx = f[0], hx = f[1], ly = f[4], hy = f[5], lz = f[8], hz = f[9];
+        F3 c, h;
+        c.x = (float) ((0.5 * ((double) lx + (double) hx)) - eye.x); c.y = (float) ((0.5 * ((double) ly + (double) hy)) - eye.y); c.z = (float) ((0.5 * ((double) lz + (double) hz)) - eye.z);
+        h.x = 0.5f * __builtin_fabsf(hx - lx) + 1e-30f; h.y = 0.5f * __builtin_fabsf(hy - ly) + 1e-30f; h.z = 0.5f * __builtin_fabsf(hz - lz) + 1e-30f;
+        h.x += 0x1p-22f * (__builtin_fabsf(lx) + __builtin_fabsf(hx)); h.y += 0x1p-22f * (__builtin_fabsf(ly) + __builtin_fabsf(hy)); h.z += 0x1p-22f * (__builtin_fabsf(lz) + __builtin_fabsf(hz)); // hx - lx is rounded
+        const bool miss = outside_plane(n[0], c, h) || outside_plane(n[1], c, h) || outside_plane(n[2], c, h) || outside_plane(n[3], c, h) || outside_plane(gcf, c, h);
+        if (!miss && lk.z != 0) {
+            if (count == 4) return RTD_CAND_WALK;
+            if (count == 2) { second = pend; pend = 0u; } // the first pair is complete: it becomes the older word
+            pend = (pend >> 16) | ((uint32_t) lk.z << 16); // the queue's own push: the newer entry in the high half
+            ++count;
+        }
+        off = miss ? lk.y : lk.x;
+    }
+    if (count > 2) { const uint32_t t = second; second = pend; pend = t; } // first = entries 1-2, second = entries 3-4
+    return pend;
+  }
+}
+
 // ---- Scene.traceRay (Scene.fs:93-114), whole path on one lane (unit hooks; the render kernel interleaves bounces) -------
 template <bool LDS, bool COUNT>
 RTD_INLINE uint32_t trace_ray(const SceneView<LDS> &sc, int maxCount, V3 o, V3 d, Rng &rng, Counters &cnt) {

@@ -74,8 +74,9 @@ struct RenderParams {
 //   pix  [P][4]     row, col, pixel stream key lo, hi
 //   live [P]        compacted pixel slots for phase 2 (fused mode), or
 //   cost [P]        rays traced for the pixel in phase 1 (pass A: the cost estimate that orders pass B; pass A has no phase 2)
-#define RTD_WAVE_WORDS(P) (14u * (uint32_t) (P)) /* fused: 11 P used; pass B uses it as two slots of {acc [P][3], pix [P][4]} */
-#define RTD_WAVE_WORDS_A(P) (11u * (uint32_t) (P)) /* pass A: acc, pix, cost -- a tighter footprint, so its units can be wider */
+//   cand [P][2]     the leaves the pixel's camera rays can reach, as two queue words (pixel_candidates, rt_device.h), or RTD_CAND_WALK
+#define RTD_WAVE_WORDS(P) (18u * (uint32_t) (P)) /* fused: 13 P used; pass B: two slots of {acc [P][3], pix [P][4]}, then cand [2][P][2] */
+#define RTD_WAVE_WORDS_A(P) (13u * (uint32_t) (P)) /* pass A: acc, pix, cost, cand [P][2] -- a tighter footprint, so its units can be wider */
 
 // Wave-private LDS words: adds from many lanes may land on one word (same pixel), so they are ds_add_u32; the owner
 // lane later takes the sum and clears the word in one ds_wrxchg.  One wave's LDS operations execute in order.
@@ -230,7 +231,7 @@ struct Sched {
     }
 
     // a new (pixel, sample) item: Scene.traceOnce's ray (Scene.fs:129-150)
-    RTD_INLINE bool start_item(uint64_t pkey, uint32_t sample, int row, int col, uint32_t slot_off) {
+    RTD_INLINE bool start_item(uint64_t pkey, uint32_t sample, int row, int col, uint32_t slot_off, uint32_t cand, uint32_t cand2) {
         const unsigned long long k0 = RTD_CLK ? __builtin_amdgcn_s_memtime() : 0ull;
         struct Stamp { StageStats &ss; unsigned long long k0; RTD_INLINE ~Stamp() { if (RTD_CLK) ss.tCam += __builtin_amdgcn_s_memtime() - k0; } } stamp{ss, k0};
         rng = stream_for(pkey, sample);
@@ -242,6 +243,10 @@ struct Sched {
         if (camera_ray(*cp, row, col, rng, o, d)) {
             st = L_WALK;
             walk_begin(w, sc.first);
+            if (LDS && !COUNT && cand != RTD_CAND_WALK) { // the tree walk of this pixel's camera rays was made once (pixel_candidates)
+                w.off = end; pend = cand; pend1 = cand2;
+                if (cand == 0u) st = L_DONE; // nothing in reach: straight to the unbounded objects
+            }
             if (COUNT) cnt.rays++;
             log_ray();
             return true;
@@ -405,8 +410,10 @@ struct Sched {
                 if (RTD_CLK && __builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) ss.leaf++;
                 if (pend != 0u) {
                     int prim;
-                    if constexpr (LDS) prim = pend_pop(pend);
-                    else prim = pend_pop_wide(pend, pend1);
+                    if constexpr (LDS) {
+                        prim = pend_pop(pend);
+                        if (pend == 0u) { pend = pend1; pend1 = 0u; } // a camera ray's third and fourth candidate (start_item)
+                    } else prim = pend_pop_wide(pend, pend1);
                     leaf_test_object_exact<LDS>(sc, o, d, bestF, w, prim, implied);
                 }
                 if (RTD_CLK) { ss.tLoop += k1 - k0; ss.tLeaf += __builtin_amdgcn_s_memtime() - k1; }
@@ -520,7 +527,7 @@ struct Sched {
 // and is sample s_base + i % per of that pixel; its colour is added to accumulator slot (sample < split ? 0 : 1).
 template <bool LDS, bool COUNT, bool COST, bool TEX>
 RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsigned char *pool, RTD_AS3 unsigned char *poolLds, RTD_AS3 uint32_t *acc, const RTD_AS3 uint32_t *pix,
-                          const RTD_AS3 uint32_t *live, bool use_live, uint32_t total, uint32_t per, uint32_t s_base,
+                          const RTD_AS3 uint32_t *cand, const RTD_AS3 uint32_t *live, bool use_live, uint32_t total, uint32_t per, uint32_t s_base,
                           uint32_t split, Counters &cnt, StageStats &ss) {
     Sched<LDS, COUNT, TEX> L(p, sc, cnt, ss, pool, poolLds);
     uint32_t next = 0; // wave-uniform
@@ -549,7 +556,7 @@ RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsig
                         int row = (int) pix[slot * 4 + 0], col = (int) pix[slot * 4 + 1];
                         uint64_t pkey = (uint64_t) pix[slot * 4 + 2] | ((uint64_t) pix[slot * 4 + 3] << 32);
                         // low half: acc word, high half: pixel slot
-                        L.start_item(pkey, s, row, col, (((s < split) ? 0u : (uint32_t) p.chunk * 3u) + slot * 3u) | (slot << 16));
+                        L.start_item(pkey, s, row, col, (((s < split) ? 0u : (uint32_t) p.chunk * 3u) + slot * 3u) | (slot << 16), cand[slot * 2], cand[slot * 2 + 1]);
                     }
                 }
             }
@@ -664,6 +671,12 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
                         pix[lane * 4 + 1] = (uint32_t) ((int) c - p.max_w);
                         pix[lane * 4 + 2] = (uint32_t) pkey;
                         pix[lane * 4 + 3] = (uint32_t) (pkey >> 32);
+                        const CameraParams *cp = p.cam_ptr;
+                        asm volatile("" : "+s"(cp));
+                        uint32_t c2;
+                        const uint32_t c1 = pixel_candidates<LDS, !COUNT>(sc, *cp, p.max_h - (int) r - 1, (int) c - p.max_w, c2);
+                        wv[14u * P + (curSlot * P + lane) * 2u] = c1;
+                        wv[14u * P + (curSlot * P + lane) * 2u + 1u] = c2;
                     }
                     __builtin_amdgcn_wave_barrier();
                     curFirst = first; curNpx = npx; curNext = 0u; curTotal = npx * n2; curOut = 0u;
@@ -694,7 +707,7 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
                         const RTD_AS3 uint32_t *pix = wv + curSlot * SW + 3u * P;
                         const int row = (int) pix[j * 4 + 0], col = (int) pix[j * 4 + 1];
                         const uint64_t pkey = (uint64_t) pix[j * 4 + 2] | ((uint64_t) pix[j * 4 + 3] << 32);
-                        started = L.start_item(pkey, smp, row, col, curSlot * SW + j * 3u);
+                        started = L.start_item(pkey, smp, row, col, curSlot * SW + j * 3u, wv[14u * P + (curSlot * P + j) * 2u], wv[14u * P + (curSlot * P + j) * 2u + 1u]);
                     }
                 }
                 L.parked -= nUnA;
@@ -779,6 +792,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     RTD_AS3 uint32_t *acc = wv;
     RTD_AS3 uint32_t *pix = wv + 6u * P;
     RTD_AS3 uint32_t *live = pix + 4u * P;
+    RTD_AS3 uint32_t *cand = live + P; // (fused and pass A; pass B keeps its own behind the two slots)
     unsigned char *pool = p.park_pool + ((size_t) blockIdx.x * (BLOCK / 64) + (size_t) wave) * (size_t) RTD_PARK_ENTRY_BYTES *
                                         (size_t) (p.park + (p.park_l_lds ? 0 : p.park_l) + (TEX ? p.park : 0));
     // the Lambert pools in LDS (if any) follow the waves' scratch
@@ -823,11 +837,17 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
             pix[lane * 4 + 1] = (uint32_t) ((int) c - p.max_w);
             pix[lane * 4 + 2] = (uint32_t) pkey;
             pix[lane * 4 + 3] = (uint32_t) (pkey >> 32);
+            const CameraParams *cp = p.cam_ptr;
+            asm volatile("" : "+s"(cp));
+            uint32_t c2;
+            const uint32_t c1 = pixel_candidates<LDS, !COUNT>(sc, *cp, p.max_h - (int) r - 1, (int) c - p.max_w, c2);
+            cand[lane * 2] = c1;
+            cand[lane * 2 + 1] = c2;
         }
         __builtin_amdgcn_wave_barrier();
 
         // ---- phase 1: 2k+1 samples per pixel, sums split after sample k (Scene.fs:172-182) ----
-        run_items<LDS, COUNT, MODE == 1, TEX>(p, sc, pool, poolLds, acc, pix, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
+        run_items<LDS, COUNT, MODE == 1, TEX>(p, sc, pool, poolLds, acc, pix, cand, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
         __builtin_amdgcn_wave_barrier();
 
         // ---- decide (Scene.fs:177-188) and compact the pixels that continue ----
@@ -862,7 +882,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
 
         // ---- phase 2: the remaining spp-2k-1 samples of the surviving pixels (Scene.fs:191-192) ----
         if (MODE == 0 && nLive > 0u) {
-            run_items<LDS, COUNT, false, TEX>(p, sc, pool, poolLds, acc, pix, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
+            run_items<LDS, COUNT, false, TEX>(p, sc, pool, poolLds, acc, pix, cand, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
             __builtin_amdgcn_wave_barrier();
         }
 

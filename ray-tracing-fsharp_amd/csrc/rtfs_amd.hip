@@ -1225,6 +1225,19 @@ __global__ void __launch_bounds__(1024) k_hit_object_lds(const RenderParams p, i
     const double nanv = __builtin_nan("");
     strike[i * 3] = w.best < 0 ? nanv : sp.x; strike[i * 3 + 1] = w.best < 0 ? nanv : sp.y; strike[i * 3 + 2] = w.best < 0 ? nanv : sp.z;
 }
+// pixel_candidates (rt_device.h) for n pixels of a camera: the Leaves a pixel's camera rays can reach, as the render kernel computes
+// them once per pixel (scene staged into LDS exactly as the timed kernel stages it).  out[i*2], out[i*2+1] = the two queue words.
+__global__ void __launch_bounds__(1024) k_pixel_candidates(const RenderParams p, const CameraParams cam, int n, const int32_t *rowcol, uint32_t *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    (void) stage_scene<1024, true>(p, smem);
+    const SceneView<true> sc = make_view<true, true>(p, smem);
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t second = 0u;
+    const uint32_t first = pixel_candidates<true, true>(sc, cam, rowcol[i * 2], rowcol[i * 2 + 1], second);
+    out[i * 2] = first;
+    out[i * 2 + 1] = second;
+}
 // The single-precision filter of the timed node loop next to the exact test, box by box: out[i] = exact | filter << 1.
 // Boxes arrive as (min, max) doubles; the host rounds them outward exactly as the scene image does (rth::f32_down / f32_up).
 __global__ void k_bbox_filter(int n, const double *rays, const double *boxes, const float *boxes32, float bmax, int32_t *out) {
@@ -1494,6 +1507,44 @@ int rt_dev_hit_object_lds(int32_t device, const rt_scene *scene, int32_t n, cons
     HIP_TRY(dh.down(hit_index));
     for (int i = 0; i < n; ++i) if (hit_index[i] >= 0) hit_index[i] = scene->host.objToOrig[(size_t) hit_index[i]];
     HIP_TRY(dsk.down(strike));
+    return RT_OK;
+}
+
+int rt_dev_pixel_candidates(int32_t device, const rt_scene *scene, const rt_camera *camera, int32_t max_w, int32_t max_h, int32_t n,
+                            const int32_t *row_col, int32_t *leaves_out) {
+    if (!camera || !row_col || !leaves_out || n < 0 || max_w <= 0 || max_h <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    RenderParams p;
+    DeviceGuard guard;
+    int rc = hook_scene_params(guard, device, scene, p);
+    if (rc != RT_OK) return rc;
+    const size_t ldsBytes = scene->host.off.lds32_total;
+    if (ldsBytes > RT_LDS_BYTES || scene->host.nBounded + scene->host.nUnbounded >= 16384u) return fail(RT_ERR_UNSUPPORTED, "the scene does not fit the LDS");
+    CameraParams cam{};
+    for (int a = 0; a < 3; ++a) { cam.eye[a] = camera->view_origin[a]; cam.xo[a] = camera->xaxis_origin[a]; cam.xd[a] = camera->xaxis_dir[a]; cam.yd[a] = camera->yaxis_dir[a]; }
+    cam.vw = camera->viewport_width; cam.vh = camera->viewport_height; cam.max_w = max_w; cam.max_h = max_h;
+    DevBuf<int32_t> drc; DevBuf<uint32_t> dout;
+    HIP_TRY(drc.alloc((size_t) n * 2)); HIP_TRY(dout.alloc((size_t) n * 2));
+    HIP_TRY(drc.up(row_col));
+    HIP_TRY(hipFuncSetAttribute((const void *) k_pixel_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes));
+    if (n) hipLaunchKernelGGL(k_pixel_candidates, dim3((unsigned) ((n + 1023) / 1024)), dim3(1024), ldsBytes, 0, p, cam, n, drc.p, dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint32_t> w((size_t) n * 2);
+    HIP_TRY(dout.down(w.data()));
+    // decode: up to four hittable indices per pixel (-1 = none); leaves_out[i*4] = -2 when the pixel's camera rays walk the tree
+    for (int i = 0; i < n; ++i) {
+        int32_t *o = leaves_out + (size_t) i * 4;
+        o[0] = o[1] = o[2] = o[3] = -1;
+        if (w[(size_t) i * 2] == RTD_CAND_WALK) { o[0] = -2; continue; }
+        int k = 0;
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t word = w[(size_t) i * 2 + (size_t) h];
+            for (int half = 0; half < 2; ++half) {
+                const uint32_t e = half == 0 ? (word & 0xFFFFu) : (word >> 16);
+                if (e != 0u && k < 4) o[k++] = scene->host.objToOrig[(size_t) (e & (RTD_PEND_MARK - 1u))];
+            }
+        }
+    }
     return RT_OK;
 }
 

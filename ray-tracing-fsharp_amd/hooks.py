@@ -108,6 +108,17 @@ def hit_object_lds(scene: Scene, rays, device=0):
     return hit, strike
 
 
+def pixel_candidates(scene: Scene, camera, max_w, max_h, row_col, device=0):
+    """The Leaves the camera rays of each pixel can reach, as the timed kernel finds them once per pixel: [n, 4] hittable indices,
+    -1 padded; a row starting with -2 means "these rays walk the tree"."""
+    import ctypes as C
+    rc = _c(row_col, np.int32).reshape(-1, 2)
+    out = np.zeros((len(rc), 4), np.int32)
+    cam = camera.to_abi()
+    check(lib.rt_dev_pixel_candidates(device, scene.handle, C.byref(cam), int(max_w), int(max_h), len(rc), _i32(rc), _i32(out)))
+    return out
+
+
 def trace_ray(scene: Scene, bounce_depth, rays, rng_state, device=0):
     rays = _c(rays, np.float64).reshape(-1, 6)
     rng = _c(rng_state, np.uint32).reshape(-1, 4).copy()

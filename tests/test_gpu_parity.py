@@ -304,6 +304,60 @@ def test_leaf_box_is_implied_by_the_sphere_hit(rt, orc):
         assert 0.2 < np.mean(bounded) < 0.98  # the rays do hit, and do miss, the spheres they graze
 
 
+def test_pixel_candidates_contain_every_leaf_a_camera_ray_can_hit(rt):
+    """The timed kernel walks the tree once per PIXEL for all of its camera rays (pixel_candidates, csrc/rt_device.h): the Leaves the
+    pyramid of the pixel's rays can touch.  The set must contain every Leaf whose box any camera ray of the pixel hits under the exact
+    BoundingBox.hits -- here checked with rays through the four corners of the pixel's patch of the viewport (jitter 0 and 1, both
+    attainable: FloatProducer is inclusive at both ends), its edges, and random points, built with Scene.traceOnce's own arithmetic
+    (Scene.fs:129-144), against every Leaf box of the scene with the DEVICE's exact box test.  Cameras: the final scene's own, one
+    inside the sphere field looking along the rows (many boxes in reach, the fall-back to walking must show), one looking straight
+    down an axis, and the every-material scene's."""
+    rng = np.random.default_rng(777)
+    cases = []
+    objs, cam, w, h = scenes.small_final(pixels=60)
+    cases.append((objs, cam, w, h))
+    P, V = scenes.P, scenes.V
+    low = dataclasses.replace(rt.Camera.makeBasic(10, 1.0, 1.5, P(-10.5, 0.3, 0.45), scenes.unit(1.0, -0.01, 0.0), V(0.0, 1.0, 0.0)), BounceDepth=5)
+    cases.append((objs, low, 45, 30))
+    axis = dataclasses.replace(rt.Camera.makeBasic(10, 2.0, 1.0, P(0.5, 30.0, 0.5), scenes.unit(0.0, -1.0, 0.0), V(0.0, 0.0, 1.0)), BounceDepth=5)
+    cases.append((objs, axis, 40, 40))
+    objs2, cam2, w2, h2 = scenes.all_materials(pixels=40)
+    cases.append((objs2, cam2, w2, h2))
+    walked = total = nonempty = 0
+    for objs, cam, w, h in cases:
+        s = rt.Scene.make(objs)
+        if s.info()["lds_resident"] != 1:
+            continue
+        _, prim, boxes = s.walk_tree()
+        leaf = prim >= 0
+        lb = boxes[leaf][:, [0, 2, 4, 1, 3, 5]]  # (minx,maxx,miny,maxy,minz,maxz) -> (min xyz, max xyz)
+        lp = prim[leaf]
+        npx = 1500
+        rows = rng.integers(-h - 1, h, npx)       # row = maxH - r - 1 for r in [0, 2 maxH]
+        cols = rng.integers(-w, w + 1, npx)
+        cand = rt.hooks.pixel_candidates(s, cam, w, h, np.stack([rows, cols], axis=1))
+        a = cam.to_abi()
+        eye, xo, xd, yd = (np.array(list(v)) for v in (a.view_origin, a.xaxis_origin, a.xaxis_dir, a.yaxis_dir))
+        jit = np.concatenate([np.array([[0.0, 0.0], [1.0, 0.0], [1.0, 1.0], [0.0, 1.0], [0.5, 0.0], [1.0, 0.5], [0.5, 1.0], [0.0, 0.5]]), rng.random((8, 2))])
+        for i in range(npx):
+            total += 1
+            if cand[i, 0] == -2:
+                walked += 1
+                continue
+            lx = ((cols[i] + jit[:, 0]) * a.viewport_width) / float(w)        # Scene.fs:131-133
+            ly = ((rows[i] + jit[:, 1]) * a.viewport_height) / float(h)       # Scene.fs:135-137
+            end = (xo[None, :] + xd[None, :] * lx[:, None]) + yd[None, :] * ly[:, None]
+            d = end - eye[None, :]
+            d = d * (1.0 / np.sqrt(np.sum(d * d, axis=1)))[:, None]
+            rays = np.concatenate([np.tile(eye, (len(jit), 1)), d], axis=1)
+            hit = rt.hooks.bbox_hits(np.repeat(rays, len(lb), axis=0), np.tile(lb, (len(rays), 1))).reshape(len(rays), len(lb)).any(axis=0)
+            reach = set(int(x) for x in lp[hit])
+            have = set(int(x) for x in cand[i] if x >= 0)
+            assert reach <= have, (i, rows[i], cols[i], sorted(reach), sorted(have))
+            nonempty += bool(have)
+    assert total > 4000 and nonempty > 300 and 0 < walked < total // 2
+
+
 def test_leaf_queue_of_the_node_loop_under_pressure(rt, orc):
     """The timed variant's node loop queues hit Leaves (two 16-bit entries per lane) and stops a lane only when its queue is full.
     Rays that run through dozens of overlapping Leaf boxes -- a skewer of nested and overlapping spheres, exact duplicates among them
