@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4
+#define RT_ABI_VERSION 5 /* 5 (round 3): rt_scene_info.leaf_box_implied (was reserved), rt_dev_bbox_filter, rt_dev_pixel_candidates */
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
