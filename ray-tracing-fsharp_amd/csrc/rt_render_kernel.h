@@ -179,7 +179,9 @@ struct StageStats { // wave-uniform, COUNT variant only
 #define RTD_PARK_L_LDS_BYTES 56 /* a parked Lambert hit in LDS: strike 24, rng 16, colour, slot, bounces | inside << 31, object */
 enum { L_IDLE = 0, L_WALK = 1, L_DONE = 2, L_SLOW = 3, L_LAMB = 4, L_TEX = 5 };
 
-template <bool LDS, bool COUNT, bool TEX>
+// LOG: the kernel may be asked to log rays (rt_scene_tune's probe): only the fused mode's instantiations carry that code -- the
+// log's four kernel arguments otherwise sit in scalar registers across the whole loop of the two-pass kernels, which have none to spare
+template <bool LDS, bool COUNT, bool TEX, bool LOG>
 struct Sched {
     const RenderParams &p;
     const SceneView<LDS> &sc;
@@ -220,6 +222,7 @@ struct Sched {
     // the probe of rt_scene_tune: a thinned-out log of the rays as they start (which rays: a hash of the ray's stream state, so
     // the logged SET does not depend on scheduling; the host sorts it)
     RTD_INLINE void log_ray() {
+        if (!LOG) return;
         if (p.ray_log == nullptr) return; // wave-uniform: one scalar compare per ray outside a probe
         if (((((rng.x ^ rng.w) * 0x9E3779B1u) >> 8) & p.ray_log_mask) == 0u) {
             const unsigned int at = atomicAdd(p.ray_log_count, 1u);
@@ -525,11 +528,11 @@ struct Sched {
 
 // Trace `total` items of the current unit.  Item i belongs to pixel slot map[i / per] (or i / per when map is null)
 // and is sample s_base + i % per of that pixel; its colour is added to accumulator slot (sample < split ? 0 : 1).
-template <bool LDS, bool COUNT, bool COST, bool TEX>
+template <bool LDS, bool COUNT, bool COST, bool TEX, bool LOG>
 RTD_INLINE void run_items(const RenderParams &p, const SceneView<LDS> &sc, unsigned char *pool, RTD_AS3 unsigned char *poolLds, RTD_AS3 uint32_t *acc, const RTD_AS3 uint32_t *pix,
                           const RTD_AS3 uint32_t *cand, const RTD_AS3 uint32_t *live, bool use_live, uint32_t total, uint32_t per, uint32_t s_base,
                           uint32_t split, Counters &cnt, StageStats &ss) {
-    Sched<LDS, COUNT, TEX> L(p, sc, cnt, ss, pool, poolLds);
+    Sched<LDS, COUNT, TEX, LOG> L(p, sc, cnt, ss, pool, poolLds);
     uint32_t next = 0; // wave-uniform
     const bool fastDiv = total < (1u << 22) && per < (1u << 23); // see div_uniform
     const float perRcp = 1.0f / (float) per;
@@ -598,7 +601,7 @@ RTD_INLINE void run_stream(const RenderParams &p, const SceneView<LDS> &sc, unsi
     const uint32_t P = (uint32_t) p.chunk;
     const uint32_t SW = 7u * P; // words per slot: acc [P][3] then pix [P][4]
     const unsigned long long nList = (unsigned long long) *p.live_count;
-    Sched<LDS, COUNT, TEX> L(p, sc, cnt, ss, pool, poolLds); // slotOff: word offset from wv of the path's accumulator triple (>= SW: slot 1)
+    Sched<LDS, COUNT, TEX, false> L(p, sc, cnt, ss, pool, poolLds); // slotOff: word offset from wv of the path's accumulator triple (>= SW: slot 1)
 
     // wave-uniform: the range being handed out (cur) and the one draining (prev)
     unsigned long long curFirst = 0, prevFirst = 0;
@@ -847,7 +850,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
         __builtin_amdgcn_wave_barrier();
 
         // ---- phase 1: 2k+1 samples per pixel, sums split after sample k (Scene.fs:172-182) ----
-        run_items<LDS, COUNT, MODE == 1, TEX>(p, sc, pool, poolLds, acc, pix, cand, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
+        run_items<LDS, COUNT, MODE == 1, TEX, MODE == 0>(p, sc, pool, poolLds, acc, pix, cand, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
         __builtin_amdgcn_wave_barrier();
 
         // ---- decide (Scene.fs:177-188) and compact the pixels that continue ----
@@ -882,7 +885,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
 
         // ---- phase 2: the remaining spp-2k-1 samples of the surviving pixels (Scene.fs:191-192) ----
         if (MODE == 0 && nLive > 0u) {
-            run_items<LDS, COUNT, false, TEX>(p, sc, pool, poolLds, acc, pix, cand, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
+            run_items<LDS, COUNT, false, TEX, MODE == 0>(p, sc, pool, poolLds, acc, pix, cand, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
             __builtin_amdgcn_wave_barrier();
         }
 

@@ -749,6 +749,7 @@ int rt_scene_tune(rt_scene *scene, const rt_camera *camera, int32_t max_w, int32
         rt_render_options po{};
         po.struct_size = (uint32_t) sizeof(po);
         po.chunk_pixels = 4; // 16 rows are a few thousand pixels for 4096 waves: small units, or most waves get none and a few get the long ones
+        po.passes = 1;       // the fused kernel: the only mode whose instantiations carry the ray log (rt_render_kernel.h, Sched<.., LOG>)
         rc = launch_render(scene, &probeCam, max_w, max_h, seed, device, first, stride, nProbe, 0u, pAccum, nullptr, nullptr, &po, true, pd, &log);
         if (rc != RT_OK) return rc;
         rt_stats st;
