@@ -162,3 +162,23 @@ def test_lds_residency_is_reported(rt):
     assert rt.Scene.make(rt.sample_images.config3_final()[0]).info()["lds_resident"] == 1
     big = rt.Scene.make(scenes.many_spheres(n=2600)[0]).info()
     assert big["lds_resident"] == 0 and big["scene_bytes"] > 163840
+
+
+def test_leaf_box_implied_flag_follows_the_scene_extent(rt):
+    """rt_scene_info.leaf_box_implied: set only for scenes inside the bounds under which the timed kernel's leaf pass may take a sphere
+    hit as proof of the leaf-box hit (csrc/rt_device.h, leaf_test_object_exact): every bounded radius in (0, 100], coordinates within
+    1000, r_max * extent <= 500."""
+    S, H, P, Tex, Px = rt.SphereStyle, rt.Hittable, rt.Point.make, rt.Texture.Colour, rt.Pixel
+    lam = S.LambertReflection(0.5, Tex(Px(9, 9, 9)))
+
+    def flag(spheres):
+        return rt.Scene.make([H.Sphere(rt.Sphere.make(lam, P(*c), r)) for c, r in spheres]).info()["leaf_box_implied"]
+
+    three = [((0.0, 0.0, 0.0), 1.0), ((3.0, 0.0, 0.0), 0.5), ((0.0, 4.0, 0.0), 0.2)]
+    assert flag(three) == 1
+    assert rt.Scene.make(rt.sample_images.config3_final()[0]).info()["leaf_box_implied"] == 1
+    assert flag(three + [((0.0, 0.0, 9.0), -0.5)]) == 0            # a negative radius: inverted box (Sphere.fs:333-336)
+    assert flag(three + [((0.0, 0.0, 300.0), 150.0)]) == 0         # radius beyond 100
+    assert flag(three + [((1200.0, 0.0, 0.0), 1.0)]) == 0          # coordinates beyond 1000
+    assert flag(three + [((40.0, 0.0, 0.0), 20.0)]) == 0           # r_max * extent = 20 * 60 > 500
+    assert flag([((0.0, 0.0, 0.0), 20.0), ((1.0, 0.0, 0.0), 1.0), ((0.0, 1.0, 0.0), 1.0)]) == 1  # 20 * 20 = 400

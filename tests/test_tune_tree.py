@@ -178,3 +178,20 @@ def test_any_rays_give_a_valid_tree(seed):
     after = s.walk_tree()
     leaves = check_nary(*after)
     assert sorted(leaves) == sorted(int(p) for p in before[1] if p >= 0)
+
+
+def test_the_threaded_build_is_deterministic(orc):
+    """rt_scene_tune's host build puts the two subtrees of the upper Branches on separate threads and appends them in pre-order: the
+    tree must be the same, node for node, every time (the contract says "the same call yields the same tree"), whatever the threads'
+    timing -- ten builds of the final scene from the same rays."""
+    objs, cam, w, h = rt.sample_images.config3_final()
+    rays = probe_rays(orc, objs, cam, w, h, n=1500)
+    first = None
+    for _ in range(10):
+        s = rt.Scene.make(objs)
+        assert s.tune_rays(rays)["tuned"] == 1
+        t = s.walk_tree()
+        if first is None:
+            first = t
+        else:
+            assert all(np.array_equal(a, b) for a, b in zip(first, t))
