@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "rt_trig.h"
 
@@ -1079,7 +1080,7 @@ RTD_INLINE bool outside_plane(F3 n, F3 c, F3 h) {
 // Returns up to four reachable Leaves as two queue words (the older pair in `first`), RTD_CAND_WALK in `first` for "walk the tree".
 template <bool LDS, bool USE> RTD_INLINE uint32_t pixel_candidates(const SceneView<LDS> &sc, const CameraParams &cam, int row, int col, uint32_t &second) {
   second = 0u;
-  if constexpr (!(LDS && USE)) return RTD_CAND_WALK; // only the timed LDS variant has the queue the candidates go into
+  if constexpr (!USE) return RTD_CAND_WALK; // only the timed variants have the queue the candidates go into
   else {
     const V3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
     F3 n[4], gcf;
@@ -1109,8 +1110,10 @@ template <bool LDS, bool USE> RTD_INLINE uint32_t pixel_candidates(const SceneVi
     int count = 0;
     for (int off = sc.first; off < sc.end;) {
         const typename Ptrs<LDS>::bp rec = node_at<LDS>(sc, off);
-        const RTD_AS3 float *f = (const RTD_AS3 float *) rec;
-        const i4 lk = *(const RTD_AS3 i4 *) (rec + 48); // on_hit, on_miss, queue entry (0 for a Branch), shift
+        typedef typename std::conditional<LDS, const RTD_AS3 float *, const float *>::type fp;
+        typedef typename std::conditional<LDS, const RTD_AS3 i4 *, const i4 *>::type i4p;
+        const fp f = (fp) rec;
+        const i4 lk = *(i4p) (rec + 48); // on_hit, on_miss, queue entry (0 for a Branch), shift
         const float lx = f[0], hx = f[1], ly = f[4], hy = f[5], lz = f[8], hz = f[9];
         F3 c, h;
         c.x = (float) ((0.5 * ((double) lx + (double) hx)) - eye.x); c.y = (float) ((0.5 * ((double) ly + (double) hy)) - eye.y); c.z = (float) ((0.5 * ((double) lz + (double) hz)) - eye.z);
@@ -1118,14 +1121,19 @@ template <bool LDS, bool USE> RTD_INLINE uint32_t pixel_candidates(const SceneVi
         h.x += 0x1p-22f * (__builtin_fabsf(lx) + __builtin_fabsf(hx)); h.y += 0x1p-22f * (__builtin_fabsf(ly) + __builtin_fabsf(hy)); h.z += 0x1p-22f * (__builtin_fabsf(lz) + __builtin_fabsf(hz)); // hx - lx is rounded
         const bool miss = outside_plane(n[0], c, h) || outside_plane(n[1], c, h) || outside_plane(n[2], c, h) || outside_plane(n[3], c, h) || outside_plane(gcf, c, h);
         if (!miss && lk.z != 0) {
-            if (count == 4) return RTD_CAND_WALK;
-            if (count == 2) { second = pend; pend = 0u; } // the first pair is complete: it becomes the older word
-            pend = (pend >> 16) | ((uint32_t) lk.z << 16); // the queue's own push: the newer entry in the high half
+            if constexpr (LDS) { // two 16-bit entries per word (node_loop_lds32's queue), two words
+                if (count == 4) return RTD_CAND_WALK;
+                if (count == 2) { second = pend; pend = 0u; } // the first pair is complete: it becomes the older word
+                pend = (pend >> 16) | ((uint32_t) lk.z << 16); // the queue's own push: the newer entry in the high half
+            } else { // full-width entries (node_loop_glb32's queue): the older in `first`, the newer in `second`
+                if (count == 2) return RTD_CAND_WALK;
+                if (count == 0) pend = (uint32_t) lk.z; else second = (uint32_t) lk.z;
+            }
             ++count;
         }
         off = miss ? lk.y : lk.x;
     }
-    if (count > 2) { const uint32_t t = second; second = pend; pend = t; } // first = entries 1-2, second = entries 3-4
+    if (LDS && count > 2) { const uint32_t t = second; second = pend; pend = t; } // first = entries 1-2, second = entries 3-4
     return pend;
   }
 }

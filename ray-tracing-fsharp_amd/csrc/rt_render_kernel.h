@@ -246,7 +246,7 @@ struct Sched {
         if (camera_ray(*cp, row, col, rng, o, d)) {
             st = L_WALK;
             walk_begin(w, sc.first);
-            if (LDS && !COUNT && cand != RTD_CAND_WALK) { // the tree walk of this pixel's camera rays was made once (pixel_candidates)
+            if (!COUNT && cand != RTD_CAND_WALK) { // the tree walk of this pixel's camera rays was made once (pixel_candidates)
                 w.off = end; pend = cand; pend1 = cand2;
                 if (cand == 0u) st = L_DONE; // nothing in reach: straight to the unbounded objects
             }
