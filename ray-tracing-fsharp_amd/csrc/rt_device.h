@@ -263,6 +263,8 @@ template <bool LDS> struct SceneView {
     const double *mat; // global memory in both variants
     int n_nodes, n_bounded, n_unbounded;
     int first, end; // walk positions of the root record and of "tree exhausted" (LDS: absolute addresses; else offsets from `node`)
+    int lds_lim;    // global-memory timed variant: node32 records at offsets below this are ALSO at the same offset in LDS (node_loop_glb32)
+    int lds_thr;    // ... and a trip serves only the lanes at such records when there are at least this many of them (>= 1; 65: never)
     const TexRec *tex;
     const uint8_t *texels;
 };
@@ -602,17 +604,23 @@ RTD_INLINE void leaf_test_object(const SceneView<LDS> &sc, V3 o, V3 d, WalkCtx &
     const double a = t * t;
     if (a < c.bestF || (a == c.bestF && prim < w.best)) { c.bestF = a; w.best = prim; w.bestLen = t; }
 }
-// The same filter loop over the image in GLOBAL memory (scenes that do not fit the LDS): `off` is the record's byte offset from the
-// node32 section (the links as the host stored them), the four reads are global_load with a scalar base.  A trip waits for L2 (or L1)
-// instead of LDS, so its ~25 VALU instructions are not what it costs; the queue of pending leaves is two FULL-WIDTH entries
-// (pend0 the older, pend1 the newer; an entry is the record's third link word, RTD_PEND_MARK | object for scenes of < 16384 objects,
-// RTD_PEND_WIDE | object beyond) because such scenes may have millions of objects.
+// The same filter loop for scenes that do not fit the LDS: `off` is the record's byte offset from the start of the node32 section
+// (the links as the host stored them).  The section is ordered by depth (rt_scene.h), and its first `lim` bytes -- as many records
+// as the LDS has room for -- were copied to the START of the workgroup's LDS (stage_nodes32): a visit reads its record from LDS if
+// off < lim, from global memory (scalar base + offset) otherwise.  A trip that reads global memory waits ~3 times as long as one that
+// reads LDS, and waits as a whole: so while `thr` or more lanes stand at records in LDS the trip is theirs alone and the lanes at
+// deeper records wait where they are; with fewer, one trip serves both kinds (reads issued under complementary masks, awaited
+// together).  Every trip advances at least one lane (thr >= 1).  Measured on the bench scene's recipe with 1026 / 2705 / 6399 spheres
+// (tuned trees): 18.5 / 20.4 / 20.9 ms with every record in global memory, 17.3 / 18.9 / 19.3 with the split but every trip serving
+// all lanes, 14.3 / 15.7 / 16.2 with thr = 16 (8..24 within 2 %; a second threshold on the number of waiting lanes gave nothing).  The queue of
+// pending leaves is two FULL-WIDTH entries (pend0 the older, pend1 the newer; an entry is the record's third link word,
+// RTD_PEND_MARK | object for scenes of < 16384 objects, RTD_PEND_WIDE | object beyond): such scenes may have millions of objects.
 #define RTD_PEND_WIDE 0x80000000u
-RTD_INLINE int node_loop_glb32(int off, uint32_t &pend0, uint32_t &pend1, const unsigned char *base, int end, int stop, const WalkCtx32 &c) {
+RTD_INLINE int node_loop_glb32(int off, uint32_t &pend0, uint32_t &pend1, const unsigned char *base, int lim, int thr, int end, int stop, const WalkCtx32 &c) {
     int ax, ay, az, cnt;
-    unsigned long long save, save2;
+    unsigned long long save, save2, save3;
     asm volatile(
-        "s_waitcnt vmcnt(0)\n"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
         "1:\n"
         "  v_cmp_gt_i32 vcc, %[end], %[off]\n"
         "  v_cmp_eq_u32 %[save2], 0, %[pend1]\n"
@@ -620,42 +628,58 @@ RTD_INLINE int node_loop_glb32(int off, uint32_t &pend0, uint32_t &pend1, const 
         "  s_bcnt1_i32_b64 %[cnt], vcc\n"
         "  s_cmp_le_u32 %[cnt], %[stop]\n"
         "  s_cbranch_scc1 2f\n"
-        "  s_and_saveexec_b64 %[save], vcc\n"
+        "  s_and_saveexec_b64 %[save], vcc\n"              /* exec = the lanes that step */
         "  v_add_u32 %[ax], %[off], %[nx]\n"
         "  v_add_u32 %[ay], %[off], %[ny]\n"
         "  v_add_u32 %[az], %[off], %[nz]\n"
+        "  v_cmp_gt_i32 vcc, %[lim], %[off]\n"             /* of those, the ones whose record is in LDS (vcc is 0 for the others) */
+        "  s_bcnt1_i32_b64 %[cnt], vcc\n"
+        "  s_cmp_ge_u32 %[cnt], %[thr]\n"
+        "  s_cbranch_scc1 3f\n"
+        "  s_and_saveexec_b64 %[save2], vcc\n"             /* save2 = the stepping lanes; exec = stepping & in LDS */
+        "  ds_read_b64 v[100:101], %[ax]\n"
+        "  ds_read_b64 v[102:103], %[ay] offset:16\n"
+        "  ds_read_b64 v[104:105], %[az] offset:32\n"
+        "  ds_read_b128 v[106:109], %[off] offset:48\n"
+        "  s_andn2_b64 exec, %[save2], exec\n"             /* stepping & not in LDS */
         "  global_load_dwordx2 v[100:101], %[ax], %[base]\n"
         "  global_load_dwordx2 v[102:103], %[ay], %[base] offset:16\n"
         "  global_load_dwordx2 v[104:105], %[az], %[base] offset:32\n"
         "  global_load_dwordx4 v[106:109], %[off], %[base] offset:48\n"
-        "  s_waitcnt vmcnt(3)\n"
+        "  s_mov_b64 exec, %[save2]\n"
+        "  s_branch 4f\n"
+        "3:\n"                                             /* thr or more lanes can step out of LDS: a trip for those alone, the */
+        "  s_mov_b64 exec, vcc\n"                          /* others wait where they are (no trip waits for global memory then) */
+        "  ds_read_b64 v[100:101], %[ax]\n"
+        "  ds_read_b64 v[102:103], %[ay] offset:16\n"
+        "  ds_read_b64 v[104:105], %[az] offset:32\n"
+        "  ds_read_b128 v[106:109], %[off] offset:48\n"
+        "4:\n"
+        "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
         "  v_fma_f32 v100, v100, %[ix], %[cnx]\n"
         "  v_fma_f32 v101, v101, %[ix], %[cfx]\n"
-        "  s_waitcnt vmcnt(2)\n"
         "  v_fma_f32 v102, v102, %[iy], %[cny]\n"
         "  v_fma_f32 v103, v103, %[iy], %[cfy]\n"
-        "  s_waitcnt vmcnt(1)\n"
         "  v_fma_f32 v104, v104, %[iz], %[cnz]\n"
         "  v_fma_f32 v105, v105, %[iz], %[cfz]\n"
         "  v_max3_f32 v100, v100, v102, v104\n"
         "  v_min3_f32 v101, v101, v103, v105\n"
         "  v_max_f32 v100, 0, v100\n"
         "  v_cmp_nlt_f32 vcc, v101, v100\n"
-        "  s_waitcnt vmcnt(0)\n"
         "  v_cndmask_b32 %[off], v107, v106, vcc\n"
         "  v_cndmask_b32 v108, 0, v108, vcc\n"           /* the entry of a hit Leaf, else 0 */
-        "  v_cmp_ne_u32 %[save2], 0, v108\n"
+        "  v_cmp_ne_u32 %[save3], 0, v108\n"
         "  v_cmp_eq_u32 vcc, 0, %[pend0]\n"
-        "  s_and_b64 vcc, %[save2], vcc\n"               /* into the empty older slot */
+        "  s_and_b64 vcc, %[save3], vcc\n"               /* into the empty older slot */
         "  v_cndmask_b32 %[pend0], %[pend0], v108, vcc\n"
-        "  s_andn2_b64 vcc, %[save2], vcc\n"             /* or into the newer one */
+        "  s_andn2_b64 vcc, %[save3], vcc\n"             /* or into the newer one */
         "  v_cndmask_b32 %[pend1], %[pend1], v108, vcc\n"
         "  s_mov_b64 exec, %[save]\n"
         "  s_branch 1b\n"
         "2:\n"
         : [off] "+v"(off), [pend0] "+v"(pend0), [pend1] "+v"(pend1), [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [cnt] "=&s"(cnt), [save] "=&s"(save),
-          [save2] "=&s"(save2)
-        : [end] "s"(end), [stop] "s"(stop), [base] "s"(base), [nx] "v"(c.nX), [ny] "v"(c.nY), [nz] "v"(c.nZ), [ix] "v"(c.ix), [iy] "v"(c.iy), [iz] "v"(c.iz),
+          [save2] "=&s"(save2), [save3] "=&s"(save3)
+        : [end] "s"(end), [lim] "s"(lim), [thr] "s"(thr), [stop] "s"(stop), [base] "s"(base), [nx] "v"(c.nX), [ny] "v"(c.nY), [nz] "v"(c.nZ), [ix] "v"(c.ix), [iy] "v"(c.iy), [iz] "v"(c.iz),
           [cnx] "v"(c.cnx), [cny] "v"(c.cny), [cnz] "v"(c.cnz), [cfx] "v"(c.cfx), [cfy] "v"(c.cfy), [cfz] "v"(c.cfz)
         : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109");
     return off;

@@ -26,6 +26,7 @@ namespace rtd {
 #define RTD_MAX_PARK 256
 #define RTD_PARK_DEFAULT 64
 #ifndef RTD_PARK_L_DEFAULT
+#define RTD_HYBRID_LANES 16 /* node_loop_glb32: this many lanes at LDS-held records make a trip of their own (measured, rt_device.h) */
 #define RTD_PARK_L_DEFAULT 64 /* entries of a wave's pool of parked Lambert hits; 0: Lambert hits are shaded where they fall */
 #endif
 
@@ -49,6 +50,8 @@ struct RenderParams {
     int32_t park;                  // entries of a wave's park pool (0: rare styles are shaded in place)
     int32_t park_l;                // entries of a wave's pool of parked LAMBERT hits (0: they are shaded where they fall)
     int32_t park_l_lds;            // 1: that pool lives in the workgroup's LDS (56-byte entries behind the waves' scratch), 0: in park_pool
+    int32_t lds_node_bytes;        // LDS=false timed kernels ("hybrid"): bytes of the node32 section's first part held at the START of the LDS
+    int32_t lds_node_thr;          // ... and how many lanes at those records make a trip of their own (node_loop_glb32; 1..65)
     int32_t *accum;                // [n_rows*cols][4]
     uint8_t *rgb;                  // [n_rows*cols][3] or null
     unsigned long long *counters;  // [16]: rays, aabb, prim, refl, samples, pixels_early, -, -, then stage executions (COUNT):
@@ -103,7 +106,7 @@ template <> RTD_INLINE SceneView<true> make_view<true, false>(const RenderParams
     v.mat = (const double *) (p.scene_image + p.off.mat);
     v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
     v.first = (int) (uint32_t) (uintptr_t) v.node; v.end = v.first + v.n_nodes * RTD_NODE_BYTES; // links were made absolute at staging
-    v.tex = p.tex; v.texels = p.texels;
+    v.tex = p.tex; v.texels = p.texels; v.lds_lim = 0; v.lds_thr = 65;
     return v;
 }
 template <> RTD_INLINE SceneView<true> make_view<true, true>(const RenderParams &p, const unsigned char *lds_base) {
@@ -115,7 +118,7 @@ template <> RTD_INLINE SceneView<true> make_view<true, true>(const RenderParams 
     v.mat = (const double *) (p.scene_image + p.off.mat);
     v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
     v.first = (int) (uint32_t) (uintptr_t) v.node; v.end = v.first + v.n_nodes * RTD_NODE32_BYTES;
-    v.tex = p.tex; v.texels = p.texels;
+    v.tex = p.tex; v.texels = p.texels; v.lds_lim = 0; v.lds_thr = 65;
     return v;
 }
 template <> RTD_INLINE SceneView<false> make_view<false, true>(const RenderParams &p, const unsigned char *) { // the timed variant over global memory
@@ -127,7 +130,7 @@ template <> RTD_INLINE SceneView<false> make_view<false, true>(const RenderParam
     v.mat = (const double *) (b + p.off.mat);
     v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
     v.first = 0; v.end = v.n_nodes * RTD_NODE32_BYTES;
-    v.tex = p.tex; v.texels = p.texels;
+    v.tex = p.tex; v.texels = p.texels; v.lds_lim = 0; v.lds_thr = 65;
     return v;
 }
 template <> RTD_INLINE SceneView<false> make_view<false, false>(const RenderParams &p, const unsigned char *) {
@@ -139,7 +142,7 @@ template <> RTD_INLINE SceneView<false> make_view<false, false>(const RenderPara
     v.mat = (const double *) (b + p.off.mat);
     v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
     v.first = 0; v.end = v.n_nodes * RTD_NODE_BYTES;
-    v.tex = p.tex; v.texels = p.texels;
+    v.tex = p.tex; v.texels = p.texels; v.lds_lim = 0; v.lds_thr = 65;
     return v;
 }
 
@@ -408,7 +411,7 @@ struct Sched {
             for (;;) {
                 const unsigned long long k0 = RTD_CLK ? __builtin_amdgcn_s_memtime() : 0ull;
                 if constexpr (LDS) w.off = node_loop_lds32(w.off, pend, end, stop, f);
-                else w.off = node_loop_glb32(w.off, pend, pend1, (const unsigned char *) sc.node, end, stop, f);
+                else w.off = node_loop_glb32(w.off, pend, pend1, (const unsigned char *) sc.node, sc.lds_lim, sc.lds_thr, end, stop, f);
                 const unsigned long long k1 = RTD_CLK ? __builtin_amdgcn_s_memtime() : 0ull;
                 if (RTD_CLK && __builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) ss.leaf++;
                 if (pend != 0u) {
@@ -771,6 +774,21 @@ RTD_INLINE uint32_t stage_scene(const RenderParams &p, unsigned char *smem) {
     return sceneBytes;
 }
 
+// "Hybrid" (the timed variant of a scene that does not fit the LDS): the first p.lds_node_bytes of the node32 section -- its records
+// are ordered by depth -- go to the START of the workgroup's LDS, links untouched (byte offsets from the section's start), so that a
+// walk position below that limit is an LDS address as it is (node_loop_glb32).  Needs the dynamic LDS to start at address 0;
+// returns the bytes staged, 0 (nothing in LDS, every visit from global memory) if it does not.
+template <int BLOCK>
+RTD_INLINE uint32_t stage_nodes32(const RenderParams &p, unsigned char *smem) {
+    if ((uint32_t) (uintptr_t) (RTD_AS3 unsigned char *) smem != 0u) return 0u; // (the reservation stays unused; the host cannot know)
+    const uint32_t bytes = (uint32_t) p.lds_node_bytes;
+    const d2 *src = (const d2 *) (p.scene_image + p.off.node32);
+    RTD_AS3 d2 *dst = (RTD_AS3 d2 *) smem;
+    for (uint32_t i = threadIdx.x; i < bytes / 16u; i += BLOCK) dst[i] = src[i];
+    __syncthreads();
+    return bytes;
+}
+
 // MODE 0: fused -- a unit's pixels go through phase 1, the adaptive decision and phase 2 on one wave.
 // MODE 1: pass A -- phase 1 and the decision for every pixel; pixels that continue are appended to `pairs` with the number of
 //         rays their 2k+1 samples took (a cost estimate), the others are final.
@@ -788,8 +806,13 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     // pools' field addresses are scalar base + 32-bit lane offset instead of 64-bit vector arithmetic kept alive across the loop
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
 
-    const uint32_t sceneBytes = LDS ? stage_scene<BLOCK, !COUNT>(p, smem) : 0u;
-    const SceneView<LDS> sc = make_view<LDS, !COUNT>(p, smem);
+    // LDS part: the whole scene (LDS variants), or as much of the tree as fits (the timed variant of a larger scene), or nothing
+    const uint32_t ldsNodes = (!LDS && !COUNT) ? stage_nodes32<BLOCK>(p, smem) : 0u;
+    const uint32_t sceneBytes = LDS ? stage_scene<BLOCK, !COUNT>(p, smem) : (uint32_t) ((!LDS && !COUNT) ? p.lds_node_bytes : 0);
+    SceneView<LDS> scv = make_view<LDS, !COUNT>(p, smem);
+    scv.lds_lim = (int) ldsNodes;
+    scv.lds_thr = p.lds_node_thr;
+    const SceneView<LDS> &sc = scv;
     const uint32_t P = (uint32_t) p.chunk;
     RTD_AS3 uint32_t *wv = (RTD_AS3 uint32_t *) (smem + sceneBytes) + (size_t) wave * (MODE == 1 ? RTD_WAVE_WORDS_A(P) : RTD_WAVE_WORDS(P));
     RTD_AS3 uint32_t *acc = wv;

@@ -525,6 +525,23 @@ static void encode_image(HostScene &s) {
     int32_t *pmeta = (int32_t *) (s.image.data() + off.meta);
     double *pmat = (double *) (s.image.data() + off.mat);
     float bmax = 1e-30f;
+    // node32 records are stored in order of DEPTH (breadth first; pre-order within a level): their links are explicit, so any order
+    // walks the same, and this one keeps the records most often visited together -- the first part of the section is what the kernel
+    // holds in LDS when the whole scene does not fit (rt_render_kernel.h, "hybrid"), and what stays in L1 / L2 otherwise.
+    std::vector<uint32_t> place(nn + 1, 0); // pre-order index -> position in the node32 section; place[nn] = nn ("tree exhausted")
+    {
+        std::vector<uint32_t> depth(nn, 0), order(nn);
+        std::vector<std::pair<int32_t, uint32_t>> up; // (end of subtree, depth) of the Branches above the current node
+        for (size_t i = 0; i < nn; ++i) {
+            while (!up.empty() && (int32_t) i >= up.back().first) up.pop_back();
+            depth[i] = up.empty() ? 0u : up.back().second + 1u;
+            if (wt.prim[i] < 0) up.emplace_back(wt.skip[i], depth[i]);
+            order[i] = (uint32_t) i;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return depth[a] < depth[b]; });
+        for (size_t k = 0; k < nn; ++k) place[order[k]] = (uint32_t) k;
+        place[nn] = (uint32_t) nn;
+    }
     for (size_t i = 0; i < nn; ++i) {
         double *bx = (double *) (pnode + i * RTD_NODE_BYTES);
         int32_t *lk = (int32_t *) (pnode + i * RTD_NODE_BYTES + 96);
@@ -536,8 +553,8 @@ static void encode_image(HostScene &s) {
         lk[3] = 0;
         // the filter loop's record: the box rounded outward, {lo, hi, hi, lo} per axis; links in the queue form of node_loop_lds32:
         // a Leaf's on_hit is its on_miss (the walk goes on), the third word its queue entry, the fourth the shift that pushes it
-        float *fx = (float *) (pnode32 + i * RTD_NODE32_BYTES);
-        int32_t *lk32 = (int32_t *) (pnode32 + i * RTD_NODE32_BYTES + 48);
+        float *fx = (float *) (pnode32 + (size_t) place[i] * RTD_NODE32_BYTES);
+        int32_t *lk32 = (int32_t *) (pnode32 + (size_t) place[i] * RTD_NODE32_BYTES + 48);
         for (int a = 0; a < 3; ++a) {
             const float lo = f32_down(wt.box[i].mn[a]), hi = f32_up(wt.box[i].mx[a]);
             fx[a * 4] = lo; fx[a * 4 + 1] = hi; fx[a * 4 + 2] = hi; fx[a * 4 + 3] = lo;
@@ -545,8 +562,8 @@ static void encode_image(HostScene &s) {
             if (std::fabs(hi) > bmax) bmax = std::fabs(hi);
         }
         const bool leaf = wt.prim[i] >= 0;
-        const int32_t onMiss32 = wt.skip[i] * RTD_NODE32_BYTES;
-        lk32[0] = leaf ? onMiss32 : (int32_t) ((i + 1) * RTD_NODE32_BYTES);
+        const int32_t onMiss32 = (int32_t) (place[(size_t) wt.skip[i]] * RTD_NODE32_BYTES);
+        lk32[0] = leaf ? onMiss32 : (int32_t) (place[i + 1] * RTD_NODE32_BYTES);
         lk32[1] = onMiss32;
         // the queue entry: 16 bits for scenes the LDS loop may walk (< 16384 objects), full width beyond (global loop only)
         lk32[2] = !leaf ? 0 : (nobj < 16384u ? (int32_t) (RTD_PEND_MARK | (uint32_t) wt.prim[i]) : (int32_t) (RTD_PEND_WIDE | (uint32_t) wt.prim[i]));

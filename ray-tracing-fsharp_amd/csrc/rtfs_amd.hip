@@ -159,6 +159,22 @@ static int lambert_pool_lds(size_t &ldsBytes, int block) {
     ldsBytes += waves * RTD_PARK_L_LDS_BYTES * c;
     return (int) c;
 }
+// The timed variant of a scene that is NOT LDS-resident keeps the first records of its depth-ordered node32 section in LDS
+// (stage_nodes32, node_loop_glb32): what fits beside the waves' scratch (`ldsBytes` on entry) and a full Lambert pool.  Returns
+// the bytes (a multiple of the record size; 0 for the counting variant, whose walk reads the exact records) and adds them.
+static uint32_t hybrid_node_bytes(const rth::HostScene &h, size_t &ldsBytes, bool lds, bool count, int block, bool pool) {
+#ifdef RTD_NO_HYBRID
+    return 0u;
+#endif
+    if (lds || count) return 0u;
+    const size_t poolBytes = pool ? (size_t) (block / 64) * RTD_PARK_L_LDS_BYTES * 64u : 0u; // (a pool of 48 measured the same, of 32 2 % slower)
+    if (ldsBytes + poolBytes + RTD_NODE32_BYTES > RT_LDS_BYTES) return 0u;
+    size_t room = (RT_LDS_BYTES - ldsBytes - poolBytes) & ~(size_t) (RTD_NODE32_BYTES - 1);
+    const size_t all = (size_t) h.off.n_nodes * RTD_NODE32_BYTES;
+    if (room > all) room = all;
+    ldsBytes += room;
+    return (uint32_t) room;
+}
 struct LaunchPlan {
     int block = 1024, chunk = 16, park = 0;
     bool lds = false;
@@ -478,6 +494,8 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
     const bool tex = !h.texRecs.empty();
     render_fn fn = pick_kernel(lds, count, block, 0, tex);
     size_t ldsBytes = lds_need(h, lds, count, block, chunk);
+    p.lds_node_bytes = (int32_t) hybrid_node_bytes(h, ldsBytes, lds, count, block, p.park_l > 0);
+    p.lds_node_thr = RTD_HYBRID_LANES;
     if (p.park_l > 0) { // the fused launch's Lambert pool: in LDS if it fits (the two-pass launches decide for themselves below)
         const int cl = lambert_pool_lds(ldsBytes, block);
         if (cl) { p.park_l = cl; p.park_l_lds = 1; }
@@ -558,12 +576,14 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
             while (lds && chunkB > 1 && lds_need(h, true, count, block, chunkB) > RT_LDS_BYTES) chunkB /= 2;
             size_t ldsA = lds_need(h, lds, count, block, chunkA, true), ldsB = lds_need(h, lds, count, block, chunkB);
             if (lds && (ldsA > RT_LDS_BYTES || ldsB > RT_LDS_BYTES)) return fail(RT_ERR_HIP, "two-pass launch does not fit the LDS");
+            const uint32_t hybA = hybrid_node_bytes(h, ldsA, lds, count, block, plan.park > 0), hybB = hybrid_node_bytes(h, ldsB, lds, count, block, plan.park > 0);
             int clA = 0, clB = 0;
             if (plan.park > 0) { clA = lambert_pool_lds(ldsA, block); clB = lambert_pool_lds(ldsB, block); }
             HIP_TRY(hipFuncSetAttribute((const void *) fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsA));
             HIP_TRY(hipFuncSetAttribute((const void *) fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsB));
             RenderParams pa = p;
             pa.chunk = chunkA;
+            pa.lds_node_bytes = (int32_t) hybA; p.lds_node_bytes = (int32_t) hybB;
             pa.park_l = clA ? clA : (plan.park > 0 ? RTD_PARK_L_DEFAULT : 0); pa.park_l_lds = clA ? 1 : 0;
             p.park_l = clB ? clB : (plan.park > 0 ? RTD_PARK_L_DEFAULT : 0); p.park_l_lds = clB ? 1 : 0;
             const uint64_t unitsA = (nLocal + (uint64_t) chunkA - 1) / (uint64_t) chunkA;

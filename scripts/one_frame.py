@@ -23,6 +23,7 @@ ap.add_argument("--passes", type=int, default=0)
 ap.add_argument("--yield-lanes", type=int, default=0)
 ap.add_argument("--refill-lanes", type=int, default=0)
 ap.add_argument("--no-tune", action="store_true", help="skip rt_scene_tune")
+ap.add_argument("--grid", type=int, default=11, help="the scene's recipe over a larger grid (sample_images.randomSpheres): 16 -> 1026 spheres, 26 -> 2705")
 ap.add_argument("--stage-stats", action="store_true", help="print rt_last_stage_stats of a timed launch too (a -DRTD_STAGE_CLOCKS build fills the cycle sums)")
 a = ap.parse_args()
 rt.set_launch_config(a.block, a.chunk)
@@ -30,6 +31,10 @@ rt.set_park(a.park)
 rt.set_passes(a.passes)
 rt.set_schedule(a.yield_lanes, a.refill_lanes)
 objs, cam, w, h = rt.sample_images.config3_final(spp=a.spp, depth=a.depth, pixels=a.pixels)
+if a.grid != 11:
+    import dataclasses
+    objs, cam, w, h = rt.sample_images.randomSpheres(2024, a.spp, a.pixels, grid=a.grid)
+    cam = dataclasses.replace(cam, BounceDepth=a.depth)
 scene = rt.Scene.make(objs)
 if not a.no_tune:
     scene.tune(w, h, cam, seed=2024)

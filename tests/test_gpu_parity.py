@@ -775,6 +775,8 @@ def test_six_thousand_spheres_binned_tree_build(rt, orc):
     acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=17, threads=8)
     assert np.array_equal(res.accum, acc) and np.array_equal(res.rgb, rgb)
     assert all(res.stats[k] == st[k] for k in ("rays", "prim_tests", "reflections", "samples")) and res.stats["aabb_tests"] < st["aabb_tests"]
+    plain = s.render_rows(w, h, cam, seed=17)
+    assert np.array_equal(plain.accum, acc) and np.array_equal(plain.rgb, rgb)
 
 
 def _cpu_quota():
@@ -810,6 +812,37 @@ def test_scene_larger_than_lds_uses_the_global_memory_kernel(rt, orc):
     res = s.render_rows(w, h, cam, seed=31, counters=True)
     acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=31, threads=8)
     _assert_render_equal(res, acc, rgb, st)
+    plain = s.render_rows(w, h, cam, seed=31)  # the timed variant: filter records, the tree's upper levels in LDS, the rest from global memory
+    assert np.array_equal(plain.accum, acc) and np.array_equal(plain.rgb, rgb)
+
+
+@pytest.mark.parametrize("n,textured", [(900, False), (1300, True), (1700, False), (4000, True), (17000, False)])
+@pytest.mark.parametrize("passes", [1, 2])
+def test_tree_partly_in_lds(rt, orc, n, textured, passes):
+    """Scenes that do not fit the LDS keep the first records of their depth-ordered filter tree there (node_loop_glb32): sizes where
+    the whole tree still fits (900), where the split falls in the lower levels (1300, 1700), where it falls high (4000), and beyond the
+    16384 objects a 14-bit queue entry can name (17000); fused and two-pass launches (their LDS budgets differ); as built and tuned
+    (the tuner reorders and thins the tree, so the split moves).  Timed variant against the oracle, every pixel."""
+    objs, cam, w, h = scenes.many_spheres(n=n, seed=40 + n % 7, spp=20, depth=10, pixels=12)
+    objs = list(objs)
+    chk = rt.ParameterisedTexture.Checkered(rt.ParameterisedTexture.UvRamp("u", 40, "v"), rt.ParameterisedTexture.Colour(rt.Pixel(20, 60, 20)), 30.0)
+    centre = rt.Point.make(0.0, 1.0, 2.0)  # with one parameterised texture the launches below are the textured kernel variants
+    if textured:
+        objs[3] = rt.Hittable.Sphere(rt.Sphere.make(rt.SphereStyle.LambertReflection(0.8, rt.ParameterisedTexture.toTexture((0.9, centre), chk)), centre, 0.9))
+    s = rt.Scene.make(objs)
+    assert s.info()["lds_resident"] == 0
+    acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=5, threads=8)
+    try:
+        rt.set_passes(passes)
+        plain = s.render_rows(w, h, cam, seed=5)
+        assert np.array_equal(plain.accum, acc) and np.array_equal(plain.rgb, rgb), "as built"
+        s.tune(w, h, cam, seed=5)
+        tuned = s.render_rows(w, h, cam, seed=5)
+        assert np.array_equal(tuned.accum, acc) and np.array_equal(tuned.rgb, rgb), "tuned"
+        counted = s.render_rows(w, h, cam, seed=5, counters=True)
+        assert np.array_equal(counted.accum, acc) and all(counted.stats[k] == st[k] for k in ("rays", "prim_tests", "reflections", "samples"))
+    finally:
+        rt.set_passes(0)
 
 
 @pytest.mark.parametrize("seed", range(40))
