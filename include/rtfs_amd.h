@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 5 /* 5 (round 3): rt_scene_info.leaf_box_implied (was reserved), rt_dev_bbox_filter, rt_dev_pixel_candidates */
+#define RT_ABI_VERSION 6 /* 5 (round 3): rt_scene_info.leaf_box_implied (was reserved), rt_dev_bbox_filter, rt_dev_pixel_candidates;
+                          * 6: rt_scene_get_filter_tree */
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
@@ -170,6 +171,14 @@ int rt_scene_get_tree(const rt_scene *scene, int32_t *skip, int32_t *prim, doubl
  * RT_WALK_TREE_REFERENCE; under RT_WALK_TREE_SAH another binary tree over the same Leaf boxes, every Branch box again the
  * exact union of the Leaf boxes below it. */
 int rt_scene_get_walk_tree(const rt_scene *scene, int32_t *skip, int32_t *prim, double *boxes);
+/* The same tree as the TIMED kernel walks it (csrc/rt_device.h, "the node loop of the timed variant"): walk_tree_nodes records in the
+ * order the device image stores them -- by depth, so that the top of the tree is a prefix (what a scene too large for the LDS keeps
+ * there) -- with explicit links.  boxes[p*6 ..] = lo, hi per axis in single precision, rounded outward from the walk tree's boxes;
+ * links[p*5 ..] = { record visited after a hit, record visited after a miss, queue entry of a Leaf (0 for a Branch: 0x4000 | index
+ * in the image's object order, or 0x80000000 | index from 16384 objects), shift that pushes it, the Leaf's hittable as an index
+ * into rt_scene_create's input (-1 for a Branch) }, records counted from 0, walk_tree_nodes = "tree exhausted".  A Leaf's two links are equal (its exact tests are queued, the walk goes on).  Host-side
+ * only (no device needed): for tests of the layout; the format is this build's, not part of the boundary's contract. */
+int rt_scene_get_filter_tree(const rt_scene *scene, float *boxes, int32_t *links);
 
 /* ---- Tuning the walk tree to a camera (no counterpart in the reference: BoundingBoxTree.make knows no rays) ----------
  * Renders a PROBE with the scene as it stands -- 16 image rows spread over the frame, through the counting kernel, which logs a

@@ -2,7 +2,7 @@
 tests/test_abi.py checks sizes against the values compiled into the library (rt_abi_sizeof)."""
 import ctypes as C
 
-RT_ABI_VERSION = 5
+RT_ABI_VERSION = 6
 
 RT_OK, RT_ERR_INVALID_ARGUMENT, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_IO = range(6)
 

@@ -73,6 +73,7 @@ SIGNATURES = {
     "rt_scene_get_info": (C.c_int, [C.c_void_p, _P(A.rt_scene_info)]),
     "rt_scene_get_tree": (C.c_int, [C.c_void_p, _i32p, _i32p, _dp]),
     "rt_scene_get_walk_tree": (C.c_int, [C.c_void_p, _i32p, _i32p, _dp]),
+    "rt_scene_get_filter_tree": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), _i32p]),
     "rt_scene_tune_rays": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _P(A.rt_tune_info)]),
     "rt_scene_tune": (C.c_int, [C.c_void_p, _P(A.rt_camera), C.c_int32, C.c_int32, C.c_uint64, C.c_int32, _P(A.rt_tune_info)]),
     "rt_render": (C.c_int, [C.c_void_p, _P(A.rt_camera), C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.c_int32,

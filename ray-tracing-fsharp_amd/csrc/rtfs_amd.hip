@@ -392,6 +392,26 @@ int rt_scene_get_walk_tree(const rt_scene *s, int32_t *skip, int32_t *prim, doub
     return copy_tree(s->host, s->host.walkTree, skip, prim, boxes);
 }
 
+int rt_scene_get_filter_tree(const rt_scene *s, float *boxes, int32_t *links) {
+    if (!s) return fail(RT_ERR_INVALID_ARGUMENT, "NULL scene");
+    if (!boxes || !links) return fail(RT_ERR_INVALID_ARGUMENT, "NULL output");
+    const rth::HostScene &h = s->host;
+    const unsigned char *sec = h.image.data() + h.off.node32;
+    for (int32_t p = 0; p < h.off.n_nodes; ++p) {
+        const float *fx = (const float *) (sec + (size_t) p * RTD_NODE32_BYTES);
+        const int32_t *lk = (const int32_t *) (sec + (size_t) p * RTD_NODE32_BYTES + 48);
+        for (int a = 0; a < 3; ++a) { boxes[(size_t) p * 6 + 2 * a] = fx[a * 4]; boxes[(size_t) p * 6 + 2 * a + 1] = fx[a * 4 + 1]; }
+        const uint32_t e = (uint32_t) lk[2];
+        const uint32_t obj = (e & RTD_PEND_WIDE) ? (e & ~RTD_PEND_WIDE) : (e & (RTD_PEND_MARK - 1u));
+        links[(size_t) p * 5 + 0] = lk[0] / RTD_NODE32_BYTES;
+        links[(size_t) p * 5 + 1] = lk[1] / RTD_NODE32_BYTES;
+        links[(size_t) p * 5 + 2] = lk[2];
+        links[(size_t) p * 5 + 3] = lk[3];
+        links[(size_t) p * 5 + 4] = e == 0u ? -1 : (obj < h.objToOrig.size() ? h.objToOrig[obj] : -2);
+    }
+    return RT_OK;
+}
+
 static int check_geometry(const rt_camera *camera, int32_t max_w, int32_t max_h, int32_t row_first, int32_t row_stride, int32_t n_rows) {
     if (!camera) return fail(RT_ERR_INVALID_ARGUMENT, "camera is NULL");
     if (max_w <= 0 || max_h <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "max_width_coord and max_height_coord must be positive");

@@ -438,6 +438,14 @@ class Scene:
         check(lib.rt_scene_get_walk_tree(self._h, _i32(skip), _i32(prim), _f64(boxes)))
         return skip, prim, boxes
 
+    def filter_tree(self):
+        """rt_scene_get_filter_tree: the timed kernel's single-precision records in the device image's (depth) order:
+        boxes [n, 6] float32 (lo, hi per axis, rounded outward), links [n, 5] int32 (on hit, on miss, queue entry, shift, hittable)."""
+        n = self.info()["walk_tree_nodes"]
+        boxes = np.zeros((n, 6), np.float32); links = np.zeros((n, 5), np.int32)
+        check(lib.rt_scene_get_filter_tree(self._h, boxes.ctypes.data_as(C.POINTER(C.c_float)), _i32(links)))
+        return boxes, links
+
     def tune(self, maxWidthCoord: int, maxHeightCoord: int, camera: Camera, *, seed: int = 0, device: int = 0) -> dict:
         """rt_scene_tune: the walk tree rebuilt from the rays of a small probe render with this camera (same pixels, fewer box tests)."""
         info = A.rt_tune_info()

@@ -1,10 +1,11 @@
-"""Long-running fuzz of the HIP path against the oracle (run by hand on a GPU box: `python tests/fuzz_campaign.py [n_scenes] [first_seed]`;
+"""Long-running fuzz of the HIP path against the oracle (run by hand on a GPU box: `python tests/fuzz_campaign.py [n_scenes] [first_seed] [large]`;
 the pytest suite runs a 40-scene slice of the same idea).  Scenes: 3-60 bounded spheres of every style, overlapping and nested, now and
 then exact duplicates (equal t^2: the tie rule), negative radii, unbounded spheres and planes, cameras anywhere, bounce depths from 0.
 Every sixth sphere or so carries a parameterised texture (checkered UV ramps, an image).  Each scene is rendered with the surface-area
 walk tree, with the reference's own tree and with the tree tuned to the scene's camera (rt_scene_tune: probe render, ray-count build,
 thinning), by the counting kernel variant (compiled node loop) and by the plain one (hand-written node loop, the one the bench
-times); all must equal the oracle bit for bit."""
+times); all must equal the oracle bit for bit.  With `large` the scenes have 900-6000 smaller spheres: they do not fit the LDS, so the
+plain variant is the one whose filter tree is split between LDS and global memory (node_loop_glb32)."""
 import dataclasses
 import os
 import sys
@@ -20,7 +21,7 @@ rt = scenes.rt
 P, V, S, PS, H, Px, Tex = scenes.P, scenes.V, scenes.S, scenes.PS, scenes.H, scenes.Px, scenes.Tex
 
 
-def scene(seed):
+def scene(seed, large=False):
     rng = np.random.default_rng(seed)
     u = lambda a, b: float(rng.uniform(a, b))  # noqa: E731
     col = lambda: Px(*(int(x) for x in rng.integers(0, 256, 3)))  # noqa: E731
@@ -40,11 +41,12 @@ def scene(seed):
         return [S.LightSource(tex), S.LambertReflection(u(0, 1), tex), S.PureReflection(u(0, 1), tex)][int(rng.integers(0, 3))]
 
     objs = []
-    n = int(rng.integers(3, 61))
+    n = int(rng.integers(900, 6001)) if large else int(rng.integers(3, 61))
     spread = u(1.0, 6.0)
+    rmax = 0.25 if large else 1.5
     for _ in range(n):
-        c, r = P(u(-spread, spread), u(-1, 2.5), u(0, 2 * spread)), u(0.05, 1.5) * (-1.0 if rng.random() < 0.08 else 1.0)
-        objs.append(H.Sphere(rt.Sphere.make(textured(c, r) if rng.random() < 0.15 else style(), c, r)))
+        c, r = P(u(-spread, spread), u(-1, 2.5), u(0, 2 * spread)), u(0.05 * rmax, rmax) * (-1.0 if rng.random() < 0.08 else 1.0)
+        objs.append(H.Sphere(rt.Sphere.make(textured(c, r) if rng.random() < (40.0 / n if large else 0.15) else style(), c, r)))
         if rng.random() < 0.1:  # an exact duplicate with another material: equal t^2
             objs.append(H.Sphere(rt.Sphere.make(style(), c, r)))
     for _ in range(int(rng.integers(0, 3))):
@@ -64,9 +66,10 @@ def scene(seed):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    large = len(sys.argv) > 3 and sys.argv[3] == "large"
     rays = 0
     for i in range(first, first + n):
-        objs, cam, w, h = scene(i)
+        objs, cam, w, h = scene(i, large)
         acc, rgb, st = orc.OracleScene(objs).render_rows(w, h, cam.to_abi(), seed=i, threads=8)
         for tree in ("sah", "reference", "tuned"):
             rt.set_walk_tree("reference" if tree == "reference" else "sah")
@@ -80,9 +83,9 @@ def main():
                 rt.set_passes(passes)
                 try:
                     res = s.render_rows(w, h, cam, seed=i, counters=True)
+                    plain = s.render_rows(w, h, cam, seed=i)
                 finally:
                     rt.set_passes(0)
-                plain = s.render_rows(w, h, cam, seed=i)
                 bad = (not np.array_equal(res.accum, acc)) or any(res.stats[k] != st[k] for k in ("rays", "prim_tests", "reflections", "samples"))
                 bad = bad or not np.array_equal(plain.accum, acc) or plain.stats["samples"] != st["samples"]
                 if tree == "reference":
@@ -91,9 +94,9 @@ def main():
                     print(f"MISMATCH scene {i} tree {tree} passes {passes}: {np.count_nonzero(np.any(res.accum != acc, axis=-1))} pixels differ", flush=True)
                     sys.exit(1)
         rays += st["rays"]
-        if (i - first) % 100 == 99:
+        if (i - first) % (20 if large else 100) == (19 if large else 99):
             print(f"{i - first + 1} scenes ok, {rays} rays", flush=True)
-    print(f"fuzz campaign: {n} scenes from seed {first}, {rays} rays, three walk trees (surface-area, reference, tuned): all equal to the oracle", flush=True)
+    print(f"fuzz campaign: {n} {'large ' if large else ''}scenes from seed {first}, {rays} rays, three walk trees (surface-area, reference, tuned): all equal to the oracle", flush=True)
 
 
 if __name__ == "__main__":

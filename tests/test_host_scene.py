@@ -182,3 +182,71 @@ def test_leaf_box_implied_flag_follows_the_scene_extent(rt):
     assert flag(three + [((1200.0, 0.0, 0.0), 1.0)]) == 0          # coordinates beyond 1000
     assert flag(three + [((40.0, 0.0, 0.0), 20.0)]) == 0           # r_max * extent = 20 * 60 > 500
     assert flag([((0.0, 0.0, 0.0), 20.0), ((1.0, 0.0, 0.0), 1.0), ((0.0, 1.0, 0.0), 1.0)]) == 1  # 20 * 20 = 400
+
+
+def _check_filter_tree(scene):
+    """rt_scene_get_filter_tree against rt_scene_get_walk_tree: same tree, records in depth order, outward-rounded boxes."""
+    import filter_cases
+    skip, prim, boxes = scene.walk_tree()
+    fb, lk = scene.filter_tree()
+    n = len(skip)
+    assert fb.shape == (n, 6) and lk.shape == (n, 5)
+    if n == 0:
+        return
+    assert np.all((lk[:, :2] >= 0) & (lk[:, :2] <= n))
+    # "every box hit" visits the records in pre-order: that walk gives each pre-order index its position in the image
+    place = np.full(n + 1, -1, np.int64)
+    place[n] = n
+    pos, seen = 0, np.zeros(n, bool)
+    for i in range(n):
+        assert 0 <= pos < n and not seen[pos], "links do not walk the tree in pre-order"
+        place[i], seen[pos] = pos, True
+        pos = int(lk[pos, 0])
+    assert pos == n and place[0] == 0                                   # the root is the first record; the walk ends at "exhausted"
+    assert sorted(place[:n].tolist()) == list(range(n))                 # a permutation: every record is reached exactly once
+    order = np.argsort(place[:n])                                       # pre-order index of the record at each position
+    leaf = prim >= 0
+    assert np.array_equal(lk[place[:n], 4], prim)                       # the same leaves, as hittable indices
+    assert np.array_equal(lk[place[:n], 1], place[skip])                # a miss skips the subtree
+    assert np.array_equal(lk[place[:n], 0][leaf], place[skip][leaf])    # a Leaf's hit link: its test is queued, the walk goes on
+    assert np.array_equal(lk[place[:n], 0][~leaf], place[1:][~leaf])    # a Branch's: its first child
+    entry = lk[place[:n], 2].astype(np.int64) & 0xFFFFFFFF
+    assert np.all(entry[~leaf] == 0) and np.all(entry[leaf] != 0)
+    assert np.all(lk[place[:n], 3][leaf] == 16) and np.all(lk[place[:n], 3][~leaf] == 0)
+    # depth never decreases along the image: the top of the tree is a prefix
+    depth = np.zeros(n, np.int64)
+    stack = []
+    for i in range(n):
+        while stack and i >= stack[-1]:
+            stack.pop()
+        depth[i] = len(stack)
+        if not leaf[i]:
+            stack.append(int(skip[i]))
+    assert np.all(np.diff(depth[order]) >= 0)
+    same = np.diff(depth[order]) == 0
+    assert np.all(np.diff(order)[same] > 0)                             # pre-order within a level
+    # boxes: the walk tree's, rounded outward once
+    assert np.array_equal(fb[place[:n]][:, 0::2], filter_cases.f32_down(boxes[:, 0::2]))
+    assert np.array_equal(fb[place[:n]][:, 1::2], filter_cases.f32_up(boxes[:, 1::2]))
+
+
+def test_filter_tree_is_the_walk_tree_in_depth_order(rt):
+    """The timed kernel's records (rt_scene_get_filter_tree): for the bench scene as built and tuned, a scene beyond the LDS, one beyond
+    16384 objects (full-width queue entries), and the degenerate sizes."""
+    objs, cam, w, h = rt.sample_images.config3_final()
+    s = rt.Scene.make(objs)
+    _check_filter_tree(s)
+    rays = scenes.random_rays(30000, 5, origin_scale=6.0)
+    s.tune_rays(rays)
+    assert s.info()["walk_tree"] == 2
+    _check_filter_tree(s)
+    big = rt.Scene.make(scenes.many_spheres(n=2600)[0])
+    _check_filter_tree(big)
+    big.tune_rays(scenes.random_rays(30000, 6, origin_scale=8.0))
+    _check_filter_tree(big)
+    wide = rt.Scene.make(scenes.many_spheres(n=17000)[0])
+    fb, lk = wide.filter_tree()
+    assert np.all((lk[lk[:, 4] >= 0, 2].astype(np.int64) & 0x80000000) != 0)
+    _check_filter_tree(wide)
+    for n in (0, 1, 2, 3):
+        _check_filter_tree(rt.Scene.make(scenes.many_spheres(n=n)[0]))
