@@ -11,7 +11,7 @@ import scenes
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("which", ["final", "all_materials", "thumb", "one", "two", "three"])
+@pytest.mark.parametrize("which", ["final", "all_materials", "thumb", "one", "two", "three", "threaded"])
 def test_flattened_tree_equals_the_pointer_tree(rt, orc, which):
     """BoundingBoxTree.make (BoundingBoxTree.fs:9-43): the product's index-array build against the oracle's recursive
     pointer build -- same pre-order, same skip links, same leaf hittables, bit-identical boxes."""
@@ -21,6 +21,9 @@ def test_flattened_tree_equals_the_pointer_tree(rt, orc, which):
         objs = scenes.all_materials()[0]
     elif which == "thumb":
         objs = scenes.small_final(seed=99)[0]
+    elif which == "threaded":  # from 4096 leaves the product builds axes and subtrees on threads (rt_scene.h): the same tree
+        objs = scenes.many_spheres(n=40000, seed=8)[0]
+        objs[100:140] = [objs[100]] * 40  # equal sort keys on every axis: the stable order decides
     else:
         n = {"one": 1, "two": 2, "three": 3}[which]
         objs = scenes.small_final()[0][:n]
