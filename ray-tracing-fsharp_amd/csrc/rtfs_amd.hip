@@ -179,8 +179,10 @@ struct LaunchPlan {
     int block = 1024, chunk = 16, park = 0;
     bool lds = false;
 };
-// Block size and residency for a scene: the preferred block if the LDS image fits beside the waves' scratch, else 256
-// threads if that fits, else the global-memory variant of the kernel at the preferred block.
+// Block size and residency for a scene: LDS-resident if its image fits beside the waves' scratch at the preferred block, else the
+// global-memory variant of the kernel at the same block (whose timed form keeps the top of the tree in LDS: hybrid_node_bytes).
+// (Until round 3 a scene that fitted only beside the scratch of a 256-thread block was kept resident with such blocks: one wave
+// per SIMD -- 899 spheres, tuned: 25.1 ms against 12.3 ms for the global-memory variant at 1024 threads.)
 static LaunchPlan plan_launch(const rth::HostScene &h, const Settings &s, bool count = false) {
     LaunchPlan p;
     p.block = s.block ? s.block : 1024;
@@ -188,9 +190,8 @@ static LaunchPlan plan_launch(const rth::HostScene &h, const Settings &s, bool c
     p.park = s.park < 0 ? 0 : (s.park ? s.park : RTD_PARK_DEFAULT);
     // (an LDS-resident scene has far fewer than the 16384 objects the node loop's 14-bit queue entries can name: 48 B each of 160 KiB)
     auto fits = [&](int block, int chunk) { return h.nBounded + h.nUnbounded < 16384u && lds_need(h, true, count, block, chunk) <= RT_LDS_BYTES; };
-    if (fits(p.block, p.chunk)) { p.lds = true; return p; }
-    if (p.block > 256 && fits(256, p.chunk)) { p.block = 256; p.lds = true; return p; }
-    return p; // global-memory variant: LDS holds only the waves' scratch, which always fits
+    if (fits(p.block, p.chunk)) p.lds = true;
+    return p; // (global-memory variant: the waves' scratch always fits)
 }
 
 // ------------------------------------------------------------------------------------------------------------
