@@ -583,11 +583,14 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
             p.live_count = (unsigned int *) (scr + 144);
             p.total_waves = (uint32_t) (fullGrid * wavesPerBlock);
             render_fn fa = pick_kernel(lds, count, block, 1, tex), fb = pick_kernel(lds, count, block, 2, tex);
-            // Unit sizes: pass A traces only 2k+1 samples per pixel, so its units are wide; pass B's largest unit is about a
+            // Unit sizes: pass A traces only 2k+1 samples per pixel, so its units are wide (below); pass B's largest unit is about a
             // sixteenth of a wave's share of the shard (measured best: 32 px at 1/2 frame, 16 at 1/4, 8 at 1/8 of config 3),
             // and shrinks towards the end of the cost-ordered list.
-            int chunkA = set.chunk ? set.chunk : 32, chunkB = set.chunk ? set.chunk : 4;
+            int chunkA = set.chunk ? set.chunk : 64, chunkB = set.chunk ? set.chunk : 4;
             if (!set.chunk) {
+                // pass A drains every unit before the next (its last paths run with most lanes idle), so wide units pay -- as long as a
+                // wave still gets seven or so of them (measured: whole frame 64 px 5.4 ms, 32 px 6.2, 16 px 8.2; an eighth: 16 px best)
+                while (chunkA > 8 && nLocal < 7ull * (uint64_t) chunkA * fullGrid * wavesPerBlock) chunkA /= 2;
                 const uint64_t share = nLocal / (fullGrid * wavesPerBlock * 16u);
                 while (chunkB < 32 && (uint64_t) chunkB * 3u / 2u <= share) chunkB *= 2; // nearest power of two
             }
@@ -595,6 +598,10 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
             // pass A would leave a half-rendered buffer); 
             while (lds && chunkA > 1 && lds_need(h, true, count, block, chunkA, true) > RT_LDS_BYTES) chunkA /= 2;
             while (lds && chunkB > 1 && lds_need(h, true, count, block, chunkB) > RT_LDS_BYTES) chunkB /= 2;
+            if (lds && plan.park > 0 && !set.chunk) { // ... and not so wide that the Lambert pool no longer fits beside them
+                auto pool_fits = [&](int c) { size_t b = lds_need(h, true, count, block, c, true); return lambert_pool_lds(b, block) != 0; };
+                while (chunkA > 16 && !pool_fits(chunkA) && pool_fits(chunkA / 2)) chunkA /= 2;
+            }
             size_t ldsA = lds_need(h, lds, count, block, chunkA, true), ldsB = lds_need(h, lds, count, block, chunkB);
             if (lds && (ldsA > RT_LDS_BYTES || ldsB > RT_LDS_BYTES)) return fail(RT_ERR_HIP, "two-pass launch does not fit the LDS");
             const uint32_t hybA = hybrid_node_bytes(h, ldsA, lds, count, block, plan.park > 0), hybB = hybrid_node_bytes(h, ldsB, lds, count, block, plan.park > 0);
