@@ -16,7 +16,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--pixels", type=int, nargs="+", default=[25, 50, 100, 200, 400, 800])
 ap.add_argument("--spp", type=int, nargs="+", default=[4, 16, 64, 256, 1000])
 ap.add_argument("--depth", type=int, default=50)
+ap.add_argument("--chunk", type=int, default=0, help="pixels per unit (0: the launch plan's own choice)")
+ap.add_argument("--passes", type=int, default=0, help="1: fused, 2: two passes (0: the launch plan's own choice)")
 a = ap.parse_args()
+rt.set_launch_config(0, a.chunk)
+rt.set_passes(a.passes)
 print("pixels  image        " + "".join(f"{s:>10d}" for s in a.spp) + "   (Mray/s per spp)")
 for px in a.pixels:
     line = ""
