@@ -106,7 +106,7 @@ template <> RTD_INLINE SceneView<true> make_view<true, false>(const RenderParams
     v.mat = (const double *) (p.scene_image + p.off.mat);
     v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
     v.first = (int) (uint32_t) (uintptr_t) v.node; v.end = v.first + v.n_nodes * RTD_NODE_BYTES; // links were made absolute at staging
-    v.tex = p.tex; v.texels = p.texels; v.lds_lim = 0; v.lds_thr = 65;
+    v.tex = p.tex; v.texels = p.texels; v.lds_lim = 0; v.lds_thr = 65; v.narrow = (v.n_bounded + v.n_unbounded) < 16384 ? 1 : 0;
     return v;
 }
 template <> RTD_INLINE SceneView<true> make_view<true, true>(const RenderParams &p, const unsigned char *lds_base) {
@@ -118,7 +118,7 @@ template <> RTD_INLINE SceneView<true> make_view<true, true>(const RenderParams 
     v.mat = (const double *) (p.scene_image + p.off.mat);
     v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
     v.first = (int) (uint32_t) (uintptr_t) v.node; v.end = v.first + v.n_nodes * RTD_NODE32_BYTES;
-    v.tex = p.tex; v.texels = p.texels; v.lds_lim = 0; v.lds_thr = 65;
+    v.tex = p.tex; v.texels = p.texels; v.lds_lim = 0; v.lds_thr = 65; v.narrow = (v.n_bounded + v.n_unbounded) < 16384 ? 1 : 0;
     return v;
 }
 template <> RTD_INLINE SceneView<false> make_view<false, true>(const RenderParams &p, const unsigned char *) { // the timed variant over global memory
@@ -130,7 +130,7 @@ template <> RTD_INLINE SceneView<false> make_view<false, true>(const RenderParam
     v.mat = (const double *) (b + p.off.mat);
     v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
     v.first = 0; v.end = v.n_nodes * RTD_NODE32_BYTES;
-    v.tex = p.tex; v.texels = p.texels; v.lds_lim = 0; v.lds_thr = 65;
+    v.tex = p.tex; v.texels = p.texels; v.lds_lim = 0; v.lds_thr = 65; v.narrow = (v.n_bounded + v.n_unbounded) < 16384 ? 1 : 0;
     return v;
 }
 template <> RTD_INLINE SceneView<false> make_view<false, false>(const RenderParams &p, const unsigned char *) {
@@ -142,7 +142,7 @@ template <> RTD_INLINE SceneView<false> make_view<false, false>(const RenderPara
     v.mat = (const double *) (b + p.off.mat);
     v.n_nodes = p.off.n_nodes; v.n_bounded = p.off.n_bounded; v.n_unbounded = p.off.n_unbounded;
     v.first = 0; v.end = v.n_nodes * RTD_NODE_BYTES;
-    v.tex = p.tex; v.texels = p.texels; v.lds_lim = 0; v.lds_thr = 65;
+    v.tex = p.tex; v.texels = p.texels; v.lds_lim = 0; v.lds_thr = 65; v.narrow = (v.n_bounded + v.n_unbounded) < 16384 ? 1 : 0;
     return v;
 }
 
@@ -411,12 +411,13 @@ struct Sched {
             for (;;) {
                 const unsigned long long k0 = RTD_CLK ? __builtin_amdgcn_s_memtime() : 0ull;
                 if constexpr (LDS) w.off = node_loop_lds32(w.off, pend, end, stop, f);
+                else if (sc.narrow) w.off = node_loop_hyb16(w.off, pend, (const unsigned char *) sc.node, sc.lds_lim, sc.lds_thr, end, stop, f);
                 else w.off = node_loop_glb32(w.off, pend, pend1, (const unsigned char *) sc.node, sc.lds_lim, sc.lds_thr, end, stop, f);
                 const unsigned long long k1 = RTD_CLK ? __builtin_amdgcn_s_memtime() : 0ull;
                 if (RTD_CLK && __builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) ss.leaf++;
                 if (pend != 0u) {
                     int prim;
-                    if constexpr (LDS) {
+                    if (LDS || sc.narrow) {
                         prim = pend_pop(pend);
                         if (pend == 0u) { pend = pend1; pend1 = 0u; } // a camera ray's third and fourth candidate (start_item)
                     } else prim = pend_pop_wide(pend, pend1);
