@@ -514,7 +514,17 @@ RTD_INLINE bool bbox_filter(const WalkCtx32 &c, float lox, float hix, float loy,
 // The loop itself, same shape as node_loop_lds: 18 VALU + 4 LDS instructions per visit, none of them double precision
 // (3 address adds, 3 ds_read_b64 + 1 ds_read_b128, 6 v_fma_f32, max3 / min3 / max, 1 compare, 2 selects, 1 v_alignbit, 2 for the
 // activity test) -- measured issue cost ~80 cycles per visit against ~147 for the double-precision loop (profiles/r3/valu_rates.txt).
-RTD_INLINE int node_loop_lds32(int off, uint32_t &pend, int end, int stop, const WalkCtx32 &c) {
+// Diagnostic builds (-DRTD_STAGE_CLOCKS) count the loop's trips and the lanes that step in them (StageStats::loopTrips, loopLanes)
+#ifdef RTD_STAGE_CLOCKS
+#define RTD_TRIP_COUNT(S) S
+#define RTD_TRIP_ARGS , unsigned &trips, unsigned &lanes
+#define RTD_TRIP_OPS , [trips] "+s"(trips), [lanes] "+s"(lanes)
+#else
+#define RTD_TRIP_COUNT(S)
+#define RTD_TRIP_ARGS
+#define RTD_TRIP_OPS
+#endif
+RTD_INLINE int node_loop_lds32(int off, uint32_t &pend, int end, int stop, const WalkCtx32 &c RTD_TRIP_ARGS) {
     int ax, ay, az, cnt;
     unsigned long long save, save2;
 #ifdef RTD_PK_FMA
@@ -532,6 +542,7 @@ RTD_INLINE int node_loop_lds32(int off, uint32_t &pend, int end, int stop, const
         "  s_cmp_le_u32 %[cnt], %[stop]\n"
         "  s_cbranch_scc1 2f\n"
         "  s_and_saveexec_b64 %[save], vcc\n"
+        RTD_TRIP_COUNT("  s_add_u32 %[trips], %[trips], 1\n  s_add_u32 %[lanes], %[lanes], %[cnt]\n")
         "  v_add_u32 %[ax], %[off], %[nx]\n"
         "  v_add_u32 %[ay], %[off], %[ny]\n"
         "  v_add_u32 %[az], %[off], %[nz]\n"
@@ -567,7 +578,7 @@ RTD_INLINE int node_loop_lds32(int off, uint32_t &pend, int end, int stop, const
         "  s_mov_b64 exec, %[save]\n"
         "  s_branch 1b\n"
         "2:\n"
-        : [off] "+v"(off), [pend] "+v"(pend), [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [cnt] "=&s"(cnt), [save] "=&s"(save), [save2] "=&s"(save2)
+        : [off] "+v"(off), [pend] "+v"(pend), [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [cnt] "=&s"(cnt), [save] "=&s"(save), [save2] "=&s"(save2) RTD_TRIP_OPS
         : [end] "s"(end), [stop] "s"(stop), [nx] "v"(c.nX), [ny] "v"(c.nY), [nz] "v"(c.nZ), [ix] "v"(c.ix), [iy] "v"(c.iy), [iz] "v"(c.iz),
           [cnx] "v"(c.cnx), [cny] "v"(c.cny), [cnz] "v"(c.cnz), [cfx] "v"(c.cfx), [cfy] "v"(c.cfy), [cfz] "v"(c.cfz)
 #ifdef RTD_PK_FMA
@@ -690,7 +701,7 @@ RTD_INLINE int node_loop_glb32(int off, uint32_t &pend0, uint32_t &pend1, const 
 // visit; and a trip that reads only LDS overlaps its arithmetic with the reads as node_loop_lds32 does.  Measured with every record
 // of a 1026-sphere scene's tree in LDS: 191 SIMD cycles per trip through node_loop_glb32 against 90 through node_loop_lds32 -- the
 // instructions around the box test, not the reads, were what such scenes paid for.
-RTD_INLINE int node_loop_hyb16(int off, uint32_t &pend, const unsigned char *base, int lim, int thr, int end, int stop, const WalkCtx32 &c) {
+RTD_INLINE int node_loop_hyb16(int off, uint32_t &pend, const unsigned char *base, int lim, int thr, int end, int stop, const WalkCtx32 &c RTD_TRIP_ARGS) {
     int ax, ay, az, cnt;
     unsigned long long save, save2;
 #define RTD_HYB_TAIL                                                                                                                  \
@@ -714,6 +725,7 @@ RTD_INLINE int node_loop_hyb16(int off, uint32_t &pend, const unsigned char *bas
         "  s_cmp_le_u32 %[cnt], %[stop]\n"
         "  s_cbranch_scc1 2f\n"
         "  s_and_saveexec_b64 %[save], vcc\n"              /* exec = the lanes that step */
+        RTD_TRIP_COUNT("  s_add_u32 %[trips], %[trips], 1\n")
         "  v_cmp_gt_i32 vcc, %[lim], %[off]\n"             /* of those, the ones whose record is in LDS (vcc is 0 for the others) */
         "  v_add_u32 %[ax], %[off], %[nx]\n"
         "  v_add_u32 %[ay], %[off], %[ny]\n"
@@ -732,6 +744,7 @@ RTD_INLINE int node_loop_hyb16(int off, uint32_t &pend, const unsigned char *bas
         "  global_load_dwordx2 v[104:105], %[az], %[base] offset:32\n"
         "  global_load_dwordx4 v[106:109], %[off], %[base] offset:48\n"
         "  s_mov_b64 exec, %[save2]\n"
+        RTD_TRIP_COUNT("  s_bcnt1_i32_b64 %[cnt], %[save2]\n  s_add_u32 %[lanes], %[lanes], %[cnt]\n")
         "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
         "  v_fma_f32 v100, v100, %[ix], %[cnx]\n"
         "  v_fma_f32 v101, v101, %[ix], %[cfx]\n"
@@ -741,6 +754,7 @@ RTD_INLINE int node_loop_hyb16(int off, uint32_t &pend, const unsigned char *bas
         "  v_fma_f32 v105, v105, %[iz], %[cfz]\n"
         RTD_HYB_TAIL
         "3:\n"                                             /* thr or more lanes can step out of LDS: a trip for those alone, the */
+        RTD_TRIP_COUNT("  s_add_u32 %[lanes], %[lanes], %[cnt]\n")
         "  s_mov_b64 exec, vcc\n"                          /* others wait where they are (no trip waits for global memory then) */
         "  ds_read_b64 v[100:101], %[ax]\n"
         "  ds_read_b64 v[102:103], %[ay] offset:16\n"
@@ -757,7 +771,7 @@ RTD_INLINE int node_loop_hyb16(int off, uint32_t &pend, const unsigned char *bas
         "  v_fma_f32 v105, v105, %[iz], %[cfz]\n"
         RTD_HYB_TAIL
         "2:\n"
-        : [off] "+v"(off), [pend] "+v"(pend), [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [cnt] "=&s"(cnt), [save] "=&s"(save), [save2] "=&s"(save2)
+        : [off] "+v"(off), [pend] "+v"(pend), [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [cnt] "=&s"(cnt), [save] "=&s"(save), [save2] "=&s"(save2) RTD_TRIP_OPS
         : [end] "s"(end), [lim] "s"(lim), [thr] "s"(thr), [stop] "s"(stop), [base] "s"(base), [nx] "v"(c.nX), [ny] "v"(c.nY), [nz] "v"(c.nZ), [ix] "v"(c.ix), [iy] "v"(c.iy), [iz] "v"(c.iz),
           [cnx] "v"(c.cnx), [cny] "v"(c.cny), [cnz] "v"(c.cnz), [cfx] "v"(c.cfx), [cfy] "v"(c.cfy), [cfz] "v"(c.cfz)
         : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109");

@@ -149,6 +149,7 @@ template <> RTD_INLINE SceneView<false> make_view<false, false>(const RenderPara
 struct StageStats { // wave-uniform, COUNT variant only
     uint32_t refill, trips, leaf, shade, refillLanes, shadeLanes, slow, slowLanes, parkedLanes;
     unsigned long long tRefill, tSlow, tWalk, tShade; // shader-clock cycles this wave spent inside each stage (s_memtime)
+    unsigned long long loopTrips, loopLanes;            // -DRTD_STAGE_CLOCKS only: trips of the timed variant's node loop, lanes that stepped in them
     unsigned long long tLoop, tLeaf, tUnb, tCam, tLamb; // -DRTD_STAGE_CLOCKS only: node loop / leaf passes (inside tWalk), unbounded tests (inside tShade),
                                                         // new items (inside tRefill), Lambert batches (inside tSlow)
 };
@@ -410,9 +411,19 @@ struct Sched {
             if (RTD_CLK) ss.trips++; // (diagnostic build: walk-stage entries and leaf passes; the loop's trips are not counted)
             for (;;) {
                 const unsigned long long k0 = RTD_CLK ? __builtin_amdgcn_s_memtime() : 0ull;
-                if constexpr (LDS) w.off = node_loop_lds32(w.off, pend, end, stop, f);
-                else if (sc.narrow) w.off = node_loop_hyb16(w.off, pend, (const unsigned char *) sc.node, sc.lds_lim, sc.lds_thr, end, stop, f);
+#ifdef RTD_STAGE_CLOCKS
+                unsigned nTrips = 0u, nLanes = 0u;
+#define RTD_TRIP_PASS , nTrips, nLanes
+#else
+#define RTD_TRIP_PASS
+#endif
+                if constexpr (LDS) w.off = node_loop_lds32(w.off, pend, end, stop, f RTD_TRIP_PASS);
+                else if (sc.narrow) w.off = node_loop_hyb16(w.off, pend, (const unsigned char *) sc.node, sc.lds_lim, sc.lds_thr, end, stop, f RTD_TRIP_PASS);
                 else w.off = node_loop_glb32(w.off, pend, pend1, (const unsigned char *) sc.node, sc.lds_lim, sc.lds_thr, end, stop, f);
+#ifdef RTD_STAGE_CLOCKS
+                ss.loopTrips += nTrips; ss.loopLanes += nLanes;
+#endif
+#undef RTD_TRIP_PASS
                 const unsigned long long k1 = RTD_CLK ? __builtin_amdgcn_s_memtime() : 0ull;
                 if (RTD_CLK && __builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) ss.leaf++;
                 if (pend != 0u) {
@@ -837,6 +848,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     StageStats ss; ss.refill = ss.trips = ss.leaf = ss.shade = ss.refillLanes = ss.shadeLanes = ss.slow = ss.slowLanes = ss.parkedLanes = 0;
     ss.tRefill = ss.tSlow = ss.tWalk = ss.tShade = 0ull;
     ss.tLoop = ss.tLeaf = ss.tUnb = ss.tCam = ss.tLamb = 0ull;
+    ss.loopTrips = ss.loopLanes = 0ull;
     uint32_t earlyCount = 0;
     uint64_t sampleCount = 0; // Scene.traceOnce calls = sum of PixelStats.Count
 
@@ -968,6 +980,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
             atomicAdd(&p.counters[29], ss.tUnb);
             atomicAdd(&p.counters[30], ss.tCam);
             atomicAdd(&p.counters[31], ss.tLamb);
+            if (!COUNT) { atomicAdd(&p.counters[14], ss.loopTrips); atomicAdd(&p.counters[15], ss.loopLanes); } // (the counting variant keeps its wave lifetimes there)
         }
     }
     if (lane == 0) {

@@ -656,7 +656,8 @@ static int collect_stats(Pending &pd, rt_stats *stats) {
     }
 #ifdef RTD_STAGE_CLOCKS
     if (getenv("RTFS_STAGE_CLOCKS")) // diagnostic build: the finer clocks of rt_render_kernel.h's StageStats
-        fprintf(stderr, "stage clocks: loop %llu leaf %llu unbounded %llu new_items %llu lambert %llu\n", c[23], c[24], c[25], c[26], c[27]);
+        fprintf(stderr, "stage clocks: loop %llu leaf %llu unbounded %llu new_items %llu lambert %llu; node loop trips %llu, lanes stepping %llu (%.1f of 64 per trip)\n",
+                c[23], c[24], c[25], c[26], c[27], c[14], c[15], c[14] ? (double) c[15] / (double) c[14] : 0.0);
 #endif
     for (int i = 0; i < 6; ++i) g_last_stage_stats[i] = c[8 + i];
     g_last_stage_stats[6] = c[14];                                  // sum of wave lifetimes, 100 MHz ticks
@@ -1272,7 +1273,12 @@ __global__ void __launch_bounds__(1024) k_hit_object_lds(const RenderParams p, i
     const bool implied = p.off.box_implied != 0 && n2 >= 1.0 - 1e-15 && n2 <= 1.0 + 1e-15;
     uint32_t pend = 0u;
     for (;;) {
+#ifdef RTD_STAGE_CLOCKS
+        unsigned nTrips = 0u, nLanes = 0u;
+        w.off = node_loop_lds32(w.off, pend, sc.end, 0, f, nTrips, nLanes);
+#else
         w.off = node_loop_lds32(w.off, pend, sc.end, 0, f); // until no lane of the wave can step: walks exhausted or queues full
+#endif
         if (__builtin_amdgcn_ballot_w64(pend != 0u) == 0ull) break;
         if (pend != 0u) leaf_test_object_exact<true>(sc, o, d, bestF, w, pend_pop(pend), implied);
     }
