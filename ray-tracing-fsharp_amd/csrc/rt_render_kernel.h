@@ -806,6 +806,8 @@ RTD_INLINE uint32_t stage_nodes32(const RenderParams &p, unsigned char *smem) {
 //         rays their 2k+1 samples took (a cost estimate), the others are final.
 // MODE 2: pass B -- phase 2 for the pixels of `live_list`, which the host-side launch sequence has ordered by decreasing cost
 //         (longest job first); run_stream.
+// MODE 3: MODE 0 with the ray log of rt_scene_tune's probe compiled in (a dozen more scalar values live across the loop: kept out
+//         of the kernels that render frames).
 // Per-pixel cost is heavy-tailed (a pixel on a glass sphere: ~20 rays per sample, 4 ms of one wave), so when a shard has only a few
 // units per wave the fused kernel ends with most waves waiting for a few long units started late; A + sort + B removes that tail.
 // Every mode computes the same integers: which wave traces which sample when has no effect (streams are per item).
@@ -813,6 +815,7 @@ RTD_INLINE uint32_t stage_nodes32(const RenderParams &p, unsigned char *smem) {
 template <bool LDS, bool COUNT, int BLOCK, int MODE, bool TEX>
 __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool FUSED = MODE == 0 || MODE == 3;
     const int lane = threadIdx.x & 63;
     // the wave's index as a SCALAR: everything derived from it (the wave's LDS scratch, its park pools) then has a scalar base, and the
     // pools' field addresses are scalar base + 32-bit lane offset instead of 64-bit vector arithmetic kept alive across the loop
@@ -886,7 +889,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
         __builtin_amdgcn_wave_barrier();
 
         // ---- phase 1: 2k+1 samples per pixel, sums split after sample k (Scene.fs:172-182) ----
-        run_items<LDS, COUNT, MODE == 1, TEX, MODE == 0>(p, sc, pool, poolLds, acc, pix, cand, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
+        run_items<LDS, COUNT, MODE == 1, TEX, MODE == 3>(p, sc, pool, poolLds, acc, pix, cand, live, false, npx * n1, n1, 0u, k + 1u, cnt, ss);
         __builtin_amdgcn_wave_barrier();
 
         // ---- decide (Scene.fs:177-188) and compact the pixels that continue ----
@@ -909,7 +912,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
         const unsigned long long liveMask = __builtin_amdgcn_ballot_w64(cont);
         const uint32_t nLive = (uint32_t) __popcll(liveMask);
         const uint32_t pos = lane_rank(liveMask);
-        if (MODE == 0) {
+        if (FUSED) {
             if (cont) live[pos] = (uint32_t) lane;
         } else if (nLive > 0u) { // pass A: hand the pixel over to pass B, with its cost estimate
             uint32_t base = 0;
@@ -920,14 +923,14 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(const RenderParams p) {
         __builtin_amdgcn_wave_barrier();
 
         // ---- phase 2: the remaining spp-2k-1 samples of the surviving pixels (Scene.fs:191-192) ----
-        if (MODE == 0 && nLive > 0u) {
-            run_items<LDS, COUNT, false, TEX, MODE == 0>(p, sc, pool, poolLds, acc, pix, cand, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
+        if (FUSED && nLive > 0u) {
+            run_items<LDS, COUNT, false, TEX, MODE == 3>(p, sc, pool, poolLds, acc, pix, cand, live, true, nLive * n2, n2, n1, 0xFFFFFFFFu, cnt, ss);
             __builtin_amdgcn_wave_barrier();
         }
 
         // ---- PixelStats and mean out: one 16-byte store per pixel ----
         if ((uint32_t) lane < npx) {
-            if (MODE == 0 && cont) {
+            if (FUSED && cont) {
                 sumR += (int) lds_take(acc + lane * 3 + 0);
                 sumG += (int) lds_take(acc + lane * 3 + 1);
                 sumB += (int) lds_take(acc + lane * 3 + 2);

@@ -216,8 +216,8 @@ template <int MODE, bool TEX> static render_fn pick_mode(bool lds, bool count, i
 }
 // tex: the scene has parameterised textures (otherwise the variant compiled without the texture call: no scratch, no VGPR spills)
 static render_fn pick_kernel(bool lds, bool count, int block, int mode, bool tex) {
-    if (tex) return mode == 0 ? pick_mode<0, true>(lds, count, block) : (mode == 1 ? pick_mode<1, true>(lds, count, block) : pick_mode<2, true>(lds, count, block));
-    return mode == 0 ? pick_mode<0, false>(lds, count, block) : (mode == 1 ? pick_mode<1, false>(lds, count, block) : pick_mode<2, false>(lds, count, block));
+    if (tex) return mode == 0 ? pick_mode<0, true>(lds, count, block) : (mode == 1 ? pick_mode<1, true>(lds, count, block) : (mode == 2 ? pick_mode<2, true>(lds, count, block) : pick_mode<3, true>(lds, count, block)));
+    return mode == 0 ? pick_mode<0, false>(lds, count, block) : (mode == 1 ? pick_mode<1, false>(lds, count, block) : (mode == 2 ? pick_mode<2, false>(lds, count, block) : pick_mode<3, false>(lds, count, block)));
 }
 
 // Zeroes a launch's counters and queues and writes its camera: one tiny launch instead of a memset plus a copy from
@@ -523,7 +523,7 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
     if (log) { p.ray_log = log->rays; p.ray_log_count = log->count; p.ray_log_cap = log->cap; p.ray_log_mask = log->mask; }
 
     const bool tex = !h.texRecs.empty();
-    render_fn fn = pick_kernel(lds, count, block, 0, tex);
+    render_fn fn = pick_kernel(lds, count, block, log ? 3 : 0, tex); // (the ray log of rt_scene_tune's probe: a kernel of its own)
     size_t ldsBytes = lds_need(h, lds, count, block, chunk);
     p.lds_node_bytes = (int32_t) hybrid_node_bytes(h, ldsBytes, lds, count, block, p.park_l > 0);
     p.lds_node_thr = RTD_HYBRID_LANES;

@@ -19,8 +19,8 @@ for d in sq1 sq2 sq3 ic fetch write; do f=$(ls $OUT/$d/*counter_collection.csv 2
 import csv, sys, collections, re
 acc = collections.defaultdict(float)
 for r in csv.DictReader(open(sys.argv[1])):
-    # the frame's own launches: not the counting variant, and not the fused mode-0 launch, which for this two-pass frame is rt_scene_tune's probe
-    if "render_kernel" in r["Kernel_Name"] and not re.search(r"render_kernel<(true|false), true", r["Kernel_Name"]) and not re.search(r"render_kernel<(true|false), (true|false), \d+, 0,", r["Kernel_Name"]):
+    # the frame's own launches: not the counting variant, and not the fused launch with the ray log (mode 3), which is rt_scene_tune's probe
+    if "render_kernel" in r["Kernel_Name"] and not re.search(r"render_kernel<(true|false), true", r["Kernel_Name"]) and not re.search(r"render_kernel<(true|false), (true|false), \d+, 3,", r["Kernel_Name"]):
         acc[r["Counter_Name"]] += float(r["Counter_Value"])
 for k, v in acc.items():
     print(f"{k},{v:.0f}")
