@@ -45,6 +45,7 @@ struct RenderParams {
     int32_t n_rows;
     int32_t k;                     // firstTrial = min 5 (spp/2)   (Scene.fs:172)
     int32_t chunk;                 // pixels per work unit, <= 64
+    int32_t leaf_wait;             // the node loop hands over to a leaf pass once this many lanes wait (>= yield_lanes, or a walk stage could spin)
     int32_t yield_lanes;           // see Sched: a stage yields once this many lanes wait for another stage
     int32_t refill_lanes;          // see Sched: idle lanes are refilled once this many are idle
     int32_t park;                  // entries of a wave's park pool (0: rare styles are shaded in place)
@@ -160,7 +161,8 @@ struct StageStats { // wave-uniform, COUNT variant only
 #else
 #define RTD_CLK false
 #endif
-#define RTD_YIELD_DEFAULT 52
+#define RTD_YIELD_DEFAULT 50
+#define RTD_LEAF_WAIT_EXTRA 5 /* RenderParams::leaf_wait = yield_lanes + this (at most 64) */
 #define RTD_REFILL_DEFAULT 8
 
 // ---- the lane scheduler shared by every render mode ------------------------------------------------------------------------
@@ -169,8 +171,9 @@ struct StageStats { // wave-uniform, COUNT variant only
 // Hittable.Reflection), SLOW (its hit needs the general `reflection`: any style but an untextured light source or Lambert sphere).
 // Per-ray work is heavy-tailed (tree nodes per ray: mean 24, p99 60, max 150), so running each stage until its slowest lane
 // finishes leaves ~70 % of the lanes idle.  Instead a stage runs while enough lanes want it:
-//   yield_lanes  the node loop yields once this many lanes are waiting for another stage (a pending leaf test, or a finished
-//                walk that wants shading); the shade stage runs once this many walks are finished (or none is left walking)
+//   yield_lanes  the walk stage yields, and the shade stage runs, once this many walks are finished (or none is left walking)
+//   leaf_wait    (yield_lanes + RTD_LEAF_WAIT_EXTRA) inside the walk stage the node loop hands over to a leaf pass once this many
+//                lanes are waiting -- for a pending leaf test, or finished.  Never below yield_lanes: the stage would spin
 //   refill_lanes idle lanes are given new work once this many are idle (or nothing else is runnable)
 // The shade stage shades the two common cases where they fall (reflection_fast) -- about 250 instructions.  The other styles'
 // code is twice as long and used to run in almost every shade stage for the two or three lanes that needed it; now such a
@@ -399,7 +402,7 @@ struct Sched {
     RTD_INLINE void stage_walk() {
         if (__builtin_amdgcn_ballot_w64(st == L_WALK) == 0ull) return;
         const int nBusy = __popcll(__builtin_amdgcn_ballot_w64(st != L_IDLE));
-        const int stop = (nBusy - p.yield_lanes) > 0 ? (nBusy - p.yield_lanes) : 0; // active <= stop  <=>  waiting >= yield
+        const int stop = (nBusy - p.leaf_wait) > 0 ? (nBusy - p.leaf_wait) : 0; // active <= stop  <=>  waiting >= leaf_wait
         if constexpr (!COUNT) {
             // the timed variant: the hand-written single-precision filter loop with its queue of pending leaves (rt_device.h) over the
             // LDS copy of the scene, or over global memory for a scene that does not fit; the leaf pass makes the sphere test and,
