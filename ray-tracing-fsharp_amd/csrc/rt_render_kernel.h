@@ -24,7 +24,7 @@ namespace rtd {
 
 #define RTD_MAX_CHUNK 64
 #define RTD_MAX_PARK 256
-#define RTD_PARK_DEFAULT 128 /* entries of a wave's general pool (88 B each, global memory): bench frame 64: 109.8 ms, 96: 108.1, 128: 107.9, 192: 108.1 */
+#define RTD_PARK_DEFAULT 96 /* entries of a wave's general pool (88 B each, global memory).  Bench frame, ms / GB written to HBM: 45: 124.6, 64: 109.7 / 14.5, 80: 108.8 / 24.0, 96: 108.2 / 28.1, 128: 108.2 / 30.7 (scripts/pool_traffic.sh) */
 #ifndef RTD_PARK_L_DEFAULT
 #define RTD_HYBRID_LANES 16 /* node_loop_glb32: this many lanes at LDS-held records make a trip of their own (measured, rt_device.h) */
 #define RTD_PARK_L_DEFAULT 64 /* entries of a wave's pool of parked Lambert hits; 0: Lambert hits are shaded where they fall */
