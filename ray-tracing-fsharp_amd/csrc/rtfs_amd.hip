@@ -478,7 +478,7 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
     const int block = plan.block;
     const bool lds = plan.lds;
     // Units of the fused kernel: 16 pixels -- except for frames of few samples per pixel (always fused: the two-pass rule below needs
-    // 128 samples in phase 2).  A unit is drained before the next, and one of 16 pixels x 11 samples is three rounds of a wave that
+    // at least 64 samples in phase 2).  A unit is drained before the next, and one of 16 pixels x 11 samples is three rounds of a wave that
     // then waits for its longest path: as wide as still leaves a wave seven units, the scene in LDS permitting (2401x1601 px:
     // 4 spp 8.5 -> 16.0 Gray/s, 16 spp 12.3 -> 19.6 with 64 pixels; 1201x801: 7.0 -> 9.3, 10.5 -> 12.5 with 32).
     int chunk = plan.chunk;
