@@ -482,7 +482,7 @@ static int launch_render(const rt_scene *scene, const rt_camera *camera, int32_t
     // then waits for its longest path: as wide as still leaves a wave seven units, the scene in LDS permitting (2401x1601 px:
     // 4 spp 8.5 -> 16.0 Gray/s, 16 spp 12.3 -> 19.6 with 64 pixels; 1201x801: 7.0 -> 9.3, 10.5 -> 12.5 with 32).
     int chunk = plan.chunk;
-    if (!set.chunk && set.passes != 2 && camera->samples_per_pixel <= 64) {
+    if (!set.chunk && set.passes != 2 && camera->samples_per_pixel <= 74) { // (below the two-pass rule's 64 samples in phase 2)
         const uint64_t px = (uint64_t) n_rows * (uint64_t) (2 * max_w + 1), waves = (uint64_t) ds->cu_count * (uint64_t) (block / 64);
         for (int c = 64; c > chunk; c /= 2)
             if (px >= 7ull * (uint64_t) c * waves && (!lds || lds_need(h, true, count, block, c) <= RT_LDS_BYTES)) { chunk = c; break; }
